@@ -1,0 +1,136 @@
+"""Pin the oracle: every oracle function against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import complex_yolov4_pytorch_amd.synthetic as syn
+from complex_yolov4_pytorch_amd.models.darknet_utils import parse_cfg
+from oracle import clip, darknet_ref, nms_ref, rotated_iou, yolo_layer_ref
+from tests.golden.make_golden import METRIC_KEYS, V4_ANCH, head_input
+
+CFG = os.path.join(os.path.dirname(__file__), '..', 'complex-yolov4-pytorch_amd', 'config', 'cfg')
+
+
+def test_known_answers(golden):
+    """SURVEY.md section 4 table (the reference's two __main__ scenarios + the disjoint bug case)."""
+    g = golden('geometry')
+    np.testing.assert_allclose(g['known_clip_area'][:3], [200.0, 375.4917, 800.0], rtol=1e-5)
+    np.testing.assert_allclose(g['giou_ious'][:3], [0.2, 0.366509, 1.0], atol=2e-6)
+    np.testing.assert_allclose(g['giou_loss'][:3], [1.030769, 0.902670, 0.6], atol=2e-6)
+    # float64 clip of the same pairs: analytic 200, and 0 for the disjoint pair
+    P, T = torch.from_numpy(g['pred'][:4]), torch.from_numpy(g['target'][:4])
+    pc = rotated_iou.box_corners(*P[:, :4].t(), torch.atan2(P[:, 4], P[:, 5])).numpy()
+    tc = rotated_iou.box_corners(*T[:, :4].t(), torch.atan2(T[:, 4], T[:, 5])).numpy()
+    inter = clip.inter_pairs(pc, tc)
+    np.testing.assert_allclose(inter[[0, 2]], [200.0, 0.0], atol=1e-4)
+    assert abs(inter[1] - 375.492) < 1e-3 and abs(inter[3] - 17.006) < 1e-3
+
+
+def test_clip_c_vs_python():
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        a = rng.uniform(-5, 5, (4, 2)).astype(np.float32)
+        b = nms_ref.corners_np(np.array([[rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(.5, 4),
+                                          rng.uniform(.5, 4), *np.sin([rng.uniform(-3, 3)]), 0.7]], np.float32))[0]
+        a = nms_ref.corners_np(np.array([[a[0, 0], a[0, 1], rng.uniform(.5, 4), rng.uniform(.5, 4), 0.3, -0.5]],
+                                        np.float32))[0]
+        assert abs(clip.inter_area(a, b) - clip.inter_area_py(a, b)) < 1e-10
+
+
+@pytest.mark.parametrize('mode', ['giou', 'iou'])
+def test_pair_iou_and_grad(golden, mode):
+    g = golden('geometry')
+    P, T = torch.from_numpy(g['pred']), torch.from_numpy(g['target'])
+    for k in range(P.shape[0]):
+        pk = P[k:k + 1].clone().requires_grad_(True)
+        ious, loss = rotated_iou.pred_vs_target(pk, T[k:k + 1], giou=(mode == 'giou'))
+        loss.backward()
+        assert abs(float(ious[0]) - g[mode + '_ious'][k]) <= 1e-5, k
+        assert abs(float(loss) - g[mode + '_loss'][k]) <= 1e-5, k
+        np.testing.assert_allclose(pk.grad[0].numpy(), g[mode + '_grad'][k], atol=2e-5, rtol=1e-4)
+    pb = P.clone().requires_grad_(True)
+    ious, loss = rotated_iou.pred_vs_target(pb, T, giou=(mode == 'giou'))
+    loss.backward()
+    np.testing.assert_allclose(loss.detach().numpy(), g[mode + '_batch_loss'], rtol=1e-5)
+    np.testing.assert_allclose(pb.grad.numpy(), g[mode + '_batch_grad'], atol=2e-5, rtol=1e-4)
+
+
+def test_disjoint_bug_is_exercised(golden):
+    """App. A #0: several random pairs must hit the reference's stale-polygon path."""
+    g = golden('geometry')
+    assert np.sum((g['giou_ious'] > g['iou_ious'] + 0.05)) >= 3
+
+
+def test_anchors_vs_targets(golden):
+    g = golden('geometry')
+    got = rotated_iou.anchors_vs_targets_iou(torch.from_numpy(g['avt_anchors']), torch.from_numpy(g['avt_targets_wlir']))
+    np.testing.assert_allclose(got.numpy(), g['avt_ious'], atol=1e-6)
+
+
+@pytest.mark.parametrize('G,mask,seed', [(19, (6, 7, 8), 0), (38, (3, 4, 5), 1)])
+@pytest.mark.parametrize('mode', ['giou', 'mse'])
+def test_yolo_head(golden, G, mask, seed, mode):
+    g = golden('yolo_head')
+    anchors = [(V4_ANCH[i][0], V4_ANCH[i][1], 0.0, 1.0) for i in mask]
+    tg = syn.targets(2, 5, 608, seed=seed, collide=True)
+    x = head_input(2, G, seed).requires_grad_(True)
+    out, loss, met = yolo_layer_ref.head_forward(x, tg, anchors, 3, 0.7, 608, mode == 'giou')
+    loss.sum().backward()
+    key = 'g%d_%s_' % (G, mode)
+    np.testing.assert_allclose(out.detach().numpy(), g[key + 'output'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(loss.detach().numpy().reshape(-1), g[key + 'loss'], rtol=1e-5)
+    np.testing.assert_allclose([met[k] for k in METRIC_KEYS], g[key + 'metrics'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), g[key + 'dx'], rtol=1e-3, atol=1e-6)
+    o2, z, _ = yolo_layer_ref.head_forward(head_input(2, G, seed), None, anchors, 3, 0.7, 608, True)
+    assert z == 0
+    np.testing.assert_allclose(o2.numpy(), g['g%d_infer_output' % G], rtol=1e-5, atol=1e-5)
+
+
+def test_nms(golden):
+    g = golden('nms')
+    pred = syn.nms_predictions(2, 3000, 160, seed=0)
+    outs, idxs = nms_ref.post_process_v2(pred, 0.5, 0.5)
+    for b in range(2):
+        ref = g['v2_img%d' % b]
+        assert outs[b].shape == ref.shape
+        np.testing.assert_array_equal(outs[b][:, 6:].numpy(), ref[:, 6:])      # obj, cls conf, cls id: exact
+        np.testing.assert_allclose(outs[b][:, :6].numpy(), ref[:, :6], rtol=1e-5, atol=1e-4)
+    assert nms_ref.post_process_v2(syn.nms_predictions(1, 500, 0, seed=1), 0.5, 0.5)[0][0] is None
+    for thr in (0.3, 0.5):
+        keep = nms_ref.greedy_nms(g['greedy_boxes'], g['greedy_confs'], thr)
+        np.testing.assert_array_equal(keep, g['greedy_keep_thr%d' % int(thr * 10)])
+    sel = pred[0][pred[0, :, 6] >= 0.5]
+    single = nms_ref.iou_matrix(sel[:1, :6].numpy(), sel[:40, :6].numpy())[0]
+    np.testing.assert_allclose(single, g['single_vs_multi'], atol=1e-6)
+
+
+@pytest.mark.parametrize('tag,cfg,B,S', [('tiny', 'complex_yolov4_tiny.cfg', 2, 608), ('v4', 'complex_yolov4.cfg', 1, 416)])
+@pytest.mark.parametrize('mode', ['giou', 'mse'])
+def test_darknet(golden, tag, cfg, B, S, mode):
+    g = golden('darknet')
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    net = darknet_ref.DarknetRef(parse_cfg(os.path.join(CFG, cfg)))
+    pshapes, bshapes = net.param_shapes()
+    key = '%s_%s_' % (tag, mode)
+    assert list(pshapes) == list(g[key + 'names'])            # state-dict parameter names and order
+    params = {k: v.requires_grad_(True) for k, v in syn.fill_state_dict(pshapes).items()}
+    bufs = syn.fill_state_dict(bshapes)
+    x, tg = syn.bev_images(B, S, seed=1), syn.targets(B, 6, S, seed=1)
+    out, loss, met = net.forward(params, x, tg, use_giou_loss=(mode == 'giou'), training=True, bufs=bufs)
+    loss.sum().backward()
+    assert list(out.shape) == list(g[key + 'out_shape'])
+    np.testing.assert_allclose(loss.detach().numpy().reshape(-1), g[key + 'loss'], rtol=2e-5)
+    np.testing.assert_allclose(out[:, ::97].detach().numpy(), g[key + 'out_rows'], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose([[m[k] for k in METRIC_KEYS] for m in met], g[key + 'metrics'], rtol=1e-3, atol=1e-5)
+    gn = np.asarray([float(params[n].grad.double().norm()) for n in pshapes])
+    np.testing.assert_allclose(gn, g[key + 'grad_norm'], rtol=2e-3, atol=1e-6)
+    bn = np.stack([bufs[str(n)][:8].numpy() for n in g[key + 'bn_names']])
+    np.testing.assert_allclose(bn, g[key + 'bn_head'], rtol=1e-4, atol=1e-6)
+    if mode == 'giou':
+        with torch.no_grad():
+            o, _, _ = net.forward(params, x, None, training=False, bufs=bufs)
+        np.testing.assert_allclose(o[:, ::97].numpy(), g['%s_eval_rows' % tag], rtol=1e-3, atol=1e-4)
