@@ -1,0 +1,47 @@
+"""Build libcyolo_hip.so in-tree with hipcc for gfx950 (no torch extension machinery: the library
+is a plain C ABI, see include/cyolo_hip.h).  Objects are cached by source mtime."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(HERE, '..', 'include')
+LIB = os.path.join(CSRC, 'libcyolo_hip.so')
+SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'elementwise.hip', 'yolo_head.hip', 'riou_nms.hip']
+HEADERS = ['common.hpp', 'geometry.hpp', os.path.join(INCLUDE, 'cyolo_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC, '-Wno-unused-value']
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    hdr_time = max(_mtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS)
+    objs, procs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _mtime(o) < max(_mtime(s), hdr_time):
+            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError('hipcc failed on %s' % src)
+    if procs or force or _mtime(LIB) < max(_mtime(o) for o in objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

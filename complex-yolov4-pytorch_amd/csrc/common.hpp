@@ -1,0 +1,112 @@
+// Shared device/host helpers for libcyolo_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cyolo_hip.h"
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define CY_WAVE 64
+
+#define CY_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return -(1000 + (int)e__);   \
+    } while (0)
+
+static inline hipStream_t cy_s(cy_stream_t s) { return (hipStream_t)s; }
+
+// ---- element traits: 16-byte chunk = CH elements ------------------------------------------------
+template <typename T>
+struct Elem;
+template <>
+struct Elem<f16> {
+    static constexpr int CH = 8;
+    static constexpr int DT = CY_F16;
+};
+template <>
+struct Elem<float> {
+    static constexpr int CH = 4;
+    static constexpr int DT = CY_F32;
+};
+
+// load/store a 16-byte chunk as CH floats
+template <typename T>
+__device__ __forceinline__ void chunk_to_f32(const u32x4& v, float* f);
+template <>
+__device__ __forceinline__ void chunk_to_f32<f16>(const u32x4& v, float* f) {
+    const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
+}
+template <>
+__device__ __forceinline__ void chunk_to_f32<float>(const u32x4& v, float* f) {
+    const f32x4 h = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = h[i];
+}
+template <typename T>
+__device__ __forceinline__ u32x4 f32_to_chunk(const float* f);
+template <>
+__device__ __forceinline__ u32x4 f32_to_chunk<f16>(const float* f) {
+    f16x8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (f16)f[i];
+    return __builtin_bit_cast(u32x4, h);
+}
+template <>
+__device__ __forceinline__ u32x4 f32_to_chunk<float>(const float* f) {
+    f32x4 h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = f[i];
+    return __builtin_bit_cast(u32x4, h);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- activations -------------------------------------------------------------------------------
+// Mish(x) = x*tanh(softplus(x)), softplus threshold 20 as torch (reference darknet2pytorch.py:22-28).
+// With n = e^x: tanh(log(1+n)) = n(n+2) / (n(n+2)+2).
+__device__ __forceinline__ float mish_f(float x) {
+    if (x > 20.f) return x;
+    const float n = expf(x);
+    const float w = n * (n + 2.f);
+    return x * (w / (w + 2.f));
+}
+__device__ __forceinline__ float mish_grad(float x) {
+    if (x > 20.f) return 1.f;
+    const float n = expf(x);
+    const float w = n * (n + 2.f);
+    const float t = w / (w + 2.f);               // tanh(softplus(x))
+    const float sg = n / (1.f + n);              // sigmoid(x)
+    return t + x * (1.f - t * t) * sg;
+}
+template <int ACT>
+__device__ __forceinline__ float act_f(float z) {
+    if (ACT == CY_ACT_MISH) return mish_f(z);
+    if (ACT == CY_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
+    return z;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z) {
+    if (ACT == CY_ACT_MISH) return mish_grad(z);
+    if (ACT == CY_ACT_LEAKY) return z > 0.f ? 1.f : 0.1f;
+    return 1.f;
+}

@@ -1,0 +1,350 @@
+// Implicit-GEMM convolution (forward and dgrad) on gfx950 MFMA.
+//
+// GEMM view:  D[co][pixel] = sum_k W[co][k] * X[pixel][k],  k = (kh,kw,c).
+// The weight tile is the MFMA A operand and the gathered activation tile the B operand, so a lane
+// ends up with 4 consecutive output channels of one pixel -> one packed NHWC store.
+//
+// Block = 256 threads = 4 waves (2 over channels x 2 over pixels); tile BN channels x BM pixels;
+// K step = one 128-byte LDS row per tile row (64 f16 / 32 f32).  Tiles are staged
+// global -> VGPR -> LDS (zero fill for padding / K tail / dgrad stride holes), double buffered, one
+// barrier per K step.  LDS rows are 128 B with the 16-byte chunk index XOR-swizzled by (row & 7):
+// conflict-free for the ds_read_b128 lane groups (see DESIGN.md section kernels).
+// f16: v_mfma_f32_16x16x32_f16.  f32 (parity mode): v_mfma_f32_16x16x4_f32, exact f32.
+#include "common.hpp"
+
+namespace {
+
+struct IgemmParams {
+    const unsigned char* g;
+    const unsigned char* w;
+    unsigned char* o;
+    const float* bias;
+    float* stats;
+    int N, GH, GW, GC, ldg;
+    int OH, OW, OC, ldo;
+    int ks, stride, pad, transposed;
+    int K, M, wrows;
+    int flags;
+    int mtiles, ntiles;
+};
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<f16> {
+    static constexpr int KSTEPS = 2;  // MFMA steps per 128-byte LDS row
+    typedef f16x8 frag;
+    __device__ static __forceinline__ frag load(const unsigned char* row_ptr, int kk, int lane) {
+        const int c = (kk * 4 + (lane >> 4)) ^ (lane & 7);
+        return *reinterpret_cast<const frag*>(row_ptr + (c << 4));
+    }
+    __device__ static __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Mma<float> {
+    static constexpr int KSTEPS = 8;
+    typedef float frag;
+    __device__ static __forceinline__ frag load(const unsigned char* row_ptr, int kk, int lane) {
+        const int c = kk ^ (lane & 7);
+        return *reinterpret_cast<const float*>(row_ptr + (c << 4) + ((lane >> 4) << 2));
+    }
+    __device__ static __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T, int BM, int BN>
+__global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int BK = 8 * CH;
+    constexpr int XR = BM / 32, WR = BN / 32;
+    constexpr int TI = BN / 32;  // channel fragments per wave (2 waves over BN)
+    constexpr int TJ = BM / 32;  // pixel fragments per wave   (2 waves over BM)
+    constexpr int STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+
+    // XCD-aware tile order: blocks that share an X tile (same pixel tile, different channel tiles)
+    // are made neighbours on one XCD's L2 (hardware places block b on XCD b % 8).
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tn = lid % p.ntiles, tm = lid / p.ntiles;
+
+    // ---- per-thread staging coordinates --------------------------------------------------------
+    const int chunk = tid & 7, rbase = tid >> 3;
+    int x_pix[XR], x_h[XR], x_w[XR];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int m = tm * BM + rbase + 32 * i;
+        if (m < p.M) {
+            const int n = m / ohw, rem = m - n * ohw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            x_pix[i] = n * p.GH * p.GW;
+            x_h[i] = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
+            x_w[i] = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
+        } else {
+            x_pix[i] = 0;
+            x_h[i] = -(1 << 20);
+            x_w[i] = -(1 << 20);
+        }
+    }
+    int k_c = chunk * CH, k_tap = 0;  // this thread's chunk: channel offset and tap within the K tile
+    while (k_c >= p.GC) { k_c -= p.GC; ++k_tap; }
+    const int ntaps = p.ks * p.ks;
+
+    u32x4 xv[XR], wv[WR];
+    auto load_tile = [&](int kt) {
+        const bool kvalid = k_tap < ntaps;
+        const int kh = (p.ks == 3) ? (k_tap * 11) >> 5 : 0;
+        const int kw = k_tap - kh * p.ks;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            int gh, gw;
+            bool ok = kvalid;
+            if (p.transposed) {
+                const int th = x_h[i] - kh, tw = x_w[i] - kw;
+                if (p.stride == 2) {
+                    ok = ok && !((th | tw) & 1);
+                    gh = th >> 1; gw = tw >> 1;
+                } else {
+                    gh = th; gw = tw;
+                }
+                ok = ok && th >= 0 && tw >= 0;
+            } else {
+                gh = x_h[i] + kh; gw = x_w[i] + kw;
+            }
+            ok = ok && gh >= 0 && gh < p.GH && gw >= 0 && gw < p.GW;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const size_t off = ((size_t)(x_pix[i] + gh * p.GW + gw) * p.ldg + k_c) * sizeof(T);
+                v = *reinterpret_cast<const u32x4*>(p.g + off);
+            }
+            xv[i] = v;
+        }
+        const int k = kt * BK + chunk * CH;
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int co = tn * BN + rbase + 32 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (kvalid && co < p.wrows) {
+                const size_t off = ((size_t)co * p.K + k) * sizeof(T);
+                v = *reinterpret_cast<const u32x4*>(p.w + off);
+            }
+            wv[i] = v;
+        }
+        // advance this thread's chunk to the next K tile
+        k_c += BK;
+        while (k_c >= p.GC) { k_c -= p.GC; ++k_tap; }
+    };
+    auto store_tile = [&](int stage) {
+        unsigned char* xs = smem + stage * STAGE;
+        unsigned char* ws = xs + BM * 128;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int row = rbase + 32 * i;
+            *reinterpret_cast<u32x4*>(xs + row * 128 + ((chunk ^ (row & 7)) << 4)) = xv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int row = rbase + 32 * i;
+            *reinterpret_cast<u32x4*>(ws + row * 128 + ((chunk ^ (row & 7)) << 4)) = wv[i];
+        }
+    };
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const unsigned char* xs = smem + cur * STAGE;
+        const unsigned char* ws = xs + BM * 128;
+        const unsigned char* wrow = ws + (wn * (BN / 2) + (lane & 15)) * 128;
+        const unsigned char* xrow = xs + (wm * (BM / 2) + (lane & 15)) * 128;
+#pragma unroll
+        for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) {
+            typename Mma<T>::frag a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = Mma<T>::load(wrow + i * 16 * 128, kk, lane);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = Mma<T>::load(xrow + j * 16 * 128, kk, lane);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // lane holds D[co = cbase + i*16 + (lane>>4)*4 + r][pixel = mbase + j*16 + (lane&15)]
+    const int cbase = tn * BN + wn * (BN / 2) + ((lane >> 4) << 2);
+    const int mbase = tm * BM + wm * (BM / 2) + (lane & 15);
+    const bool f32out = (p.flags & CY_CONV_BIAS_F32OUT) != 0;
+    const bool accum = (p.flags & CY_CONV_ACCUM) != 0;
+
+    if (p.flags & CY_CONV_STATS) {
+        float* srow = p.stats + (size_t)(tm * 2 + wm) * 2 * p.OC;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const float v = (mbase + j * 16 < p.M) ? acc[i][j][r] : 0.f;
+                    s += v;
+                    q += v * v;
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s += __shfl_xor(s, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                const int co = cbase + i * 16 + r;
+                if ((lane & 15) == 0 && co < p.OC) {
+                    srow[co] = s;
+                    srow[p.OC + co] = q;
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int m = mbase + j * 16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int co = cbase + i * 16;
+            if (co >= p.OC) continue;
+            f32x4 v = acc[i][j];
+            if (f32out) {
+                float* dst = reinterpret_cast<float*>(p.o) + (size_t)m * p.ldo + co;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < p.OC) {
+                        float t = v[r] + (p.bias ? p.bias[co + r] : 0.f);
+                        if (accum) t += dst[r];
+                        dst[r] = t;
+                    }
+            } else if (sizeof(T) == 2) {
+                f16* dst = reinterpret_cast<f16*>(p.o) + (size_t)m * p.ldo + co;
+                if (co + 3 < p.OC) {
+                    if (accum) {
+                        const f16x4 old = *reinterpret_cast<const f16x4*>(dst);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                    }
+                    f16x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (f16)v[r];
+                    *reinterpret_cast<f16x4*>(dst) = h;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.OC) dst[r] = (f16)(v[r] + (accum ? (float)dst[r] : 0.f));
+                }
+            } else {
+                float* dst = reinterpret_cast<float*>(p.o) + (size_t)m * p.ldo + co;
+                if (co + 3 < p.OC) {
+                    if (accum) {
+                        const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
+                        v += old;
+                    }
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.OC) dst[r] = v[r] + (accum ? dst[r] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+int launch(const IgemmParams& p0, hipStream_t s) {
+    IgemmParams p = p0;
+    p.mtiles = (p.M + BM - 1) / BM;
+    p.ntiles = (p.OC + BN - 1) / BN;
+    const int smem = 2 * (BM + BN) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, s, p);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tile choice: channels tile = min(128, OC rounded up to 32); pixel tile 128 unless that leaves
+// the 256 CUs under-filled.
+inline void pick_tile(int M, int OC, int& bm, int& bn) {
+    bn = OC > 64 ? 128 : (OC > 32 ? 64 : 32);
+    bm = 128;
+    const long blocks128 = (long)((M + 127) / 128) * ((OC + bn - 1) / bn);
+    if (blocks128 < 512) bm = 64;
+}
+
+template <typename T>
+int dispatch(const IgemmParams& p, hipStream_t s) {
+    int bm, bn;
+    pick_tile(p.M, p.OC, bm, bn);
+    if (bm == 128) {
+        if (bn == 128) return launch<T, 128, 128>(p, s);
+        if (bn == 64) return launch<T, 128, 64>(p, s);
+        return launch<T, 128, 32>(p, s);
+    }
+    if (bn == 128) return launch<T, 64, 128>(p, s);
+    if (bn == 64) return launch<T, 64, 64>(p, s);
+    return launch<T, 64, 32>(p, s);
+}
+
+}  // namespace
+
+extern "C" int cy_conv_stats_rows(int M, int OC) {
+    int bm, bn;
+    pick_tile(M, OC, bm, bn);
+    return 2 * ((M + bm - 1) / bm);
+}
+
+extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows,
+                             void* out, int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype,
+                             int flags, const float* bias, float* stats_part, int* stats_rows_host, cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!g || !w || !out || (dtype != CY_F16 && dtype != CY_F32)) return CY_ERR_ARG;
+    if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2) || GC % ch || ldg % ch) return CY_ERR_ARG;
+    if ((flags & CY_CONV_STATS) && !stats_part) return CY_ERR_ARG;
+    if (!(flags & CY_CONV_BIAS_F32OUT) && (ldo % 4)) return CY_ERR_ARG;
+    IgemmParams p;
+    p.g = (const unsigned char*)g; p.w = (const unsigned char*)w; p.o = (unsigned char*)out;
+    p.bias = bias; p.stats = stats_part;
+    p.N = N; p.GH = GH; p.GW = GW; p.GC = GC; p.ldg = ldg;
+    p.OH = OH; p.OW = OW; p.OC = OC; p.ldo = ldo;
+    p.ks = ks; p.stride = stride; p.pad = pad; p.transposed = (flags & CY_CONV_TRANSPOSED) ? 1 : 0;
+    p.K = ks * ks * GC; p.M = N * OH * OW; p.wrows = wrows; p.flags = flags;
+    p.mtiles = p.ntiles = 0;
+    if (p.M <= 0 || OC <= 0) return CY_ERR_ARG;
+    if (stats_rows_host) *stats_rows_host = cy_conv_stats_rows(p.M, OC);
+    return dtype == CY_F16 ? dispatch<f16>(p, cy_s(s)) : dispatch<float>(p, cy_s(s));
+}

@@ -1,0 +1,321 @@
+// Weight gradient on gfx950 MFMA:  dW[co][(tap,ci)] = sum_pixels dY[pixel][co] * X[pixel (+) tap][ci].
+//
+// The reduction index is the pixel, while both operands are stored channel-contiguous (NHWC), so each
+// MFMA fragment needs a transposed view of an LDS tile stored [pixel][channel].  f16 uses the gfx950
+// LDS transpose read ds_read_b64_tr_b16 (two per 8-element fragment); a scalar-gather path
+// (use_tr = 0) exists to pin that mapping in the test-suite.  f32 parity mode needs no transpose
+// (one element per lane).  LDS rows are padded by 32 bytes: 8 consecutive pixel rows then start on
+// distinct 32-byte bank groups, which is the access pattern of one transpose read.
+//
+// Grid = (column tiles of ks*ks*Ci, channel tiles of Co, split): split-K over pixels; each block
+// writes its own slab part[sp] (deterministic; cy_wgrad_reduce folds the slabs).
+#include "common.hpp"
+
+namespace {
+
+struct WgradParams {
+    const unsigned char* dy;
+    const unsigned char* x;
+    float* part;
+    int N, OH, OW, Co, lddy;
+    int XH, XW, Ci, ldx;
+    int ks, stride, pad;
+    int M, Ncols, CoRows;
+    int pps;  // pixels per split (multiple of BKP)
+};
+
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+template <typename T>
+struct WTraits;
+template <>
+struct WTraits<f16> {
+    static constexpr int BKP = 64;
+};
+template <>
+struct WTraits<float> {
+    static constexpr int BKP = 32;
+};
+
+template <typename T, int BCO, int BCI, bool USE_TR>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int BKP = WTraits<T>::BKP;
+    constexpr int CPR_A = BCO / CH, RPP_A = 256 / CPR_A, PASS_A = BKP / RPP_A;
+    constexpr int CPR_B = BCI / CH, RPP_B = 256 / CPR_B, PASS_B = BKP / RPP_B;
+    constexpr int RB_A = BCO * (int)sizeof(T) + 32, RB_B = BCI * (int)sizeof(T) + 32;
+    constexpr int STAGE = BKP * (RB_A + RB_B);
+    constexpr int TI = BCO / 32, TJ = BCI / 32;
+    static_assert(PASS_A >= 1 && PASS_B >= 1, "tile too narrow");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int col0 = blockIdx.x * BCI, co0 = blockIdx.y * BCO, sp = blockIdx.z;
+    const int pix_begin = sp * p.pps;
+    const int pix_end = min(p.M, pix_begin + p.pps);
+
+    // ---- staging coordinates -------------------------------------------------------------------
+    const int a_chunk = tid % CPR_A, a_row0 = tid / CPR_A;
+    const int b_chunk = tid % CPR_B, b_row0 = tid / CPR_B;
+    const int a_co = co0 + a_chunk * CH;
+    const bool a_cok = a_co < p.Co;  // Co is a multiple of CH for every caller
+    const int b_col = col0 + b_chunk * CH;
+    const bool b_cok = b_col < p.Ncols;
+    const int b_tap = b_cok ? b_col / p.Ci : 0;
+    const int b_ci = b_col - b_tap * p.Ci;
+    const int b_kh = b_tap / p.ks, b_kw = b_tap - b_kh * p.ks;
+    // pixel decomposition of this thread's B rows, advanced incrementally by BKP per K step
+    int bn[PASS_B], boh[PASS_B], bow[PASS_B];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int q = 0; q < PASS_B; ++q) {
+        const int m = pix_begin + b_row0 + q * RPP_B;
+        const int n = m / ohw, rem = m - n * ohw;
+        bn[q] = n; boh[q] = rem / p.OW; bow[q] = rem - boh[q] * p.OW;
+    }
+
+    u32x4 av[PASS_A], bv[PASS_B];
+    auto load_tile = [&](int pix0) {
+#pragma unroll
+        for (int q = 0; q < PASS_A; ++q) {
+            const int m = pix0 + a_row0 + q * RPP_A;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (a_cok && m < pix_end) v = *reinterpret_cast<const u32x4*>(p.dy + ((size_t)m * p.lddy + a_co) * sizeof(T));
+            av[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < PASS_B; ++q) {
+            const int m = pix0 + b_row0 + q * RPP_B;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int xh = boh[q] * p.stride - p.pad + b_kh, xw = bow[q] * p.stride - p.pad + b_kw;
+            if (b_cok && m < pix_end && xh >= 0 && xh < p.XH && xw >= 0 && xw < p.XW) {
+                const size_t off = ((size_t)((bn[q] * p.XH + xh) * p.XW + xw) * p.ldx + b_ci) * sizeof(T);
+                v = *reinterpret_cast<const u32x4*>(p.x + off);
+            }
+            bv[q] = v;
+            bow[q] += BKP;
+            while (bow[q] >= p.OW) { bow[q] -= p.OW; ++boh[q]; }
+            while (boh[q] >= p.OH) { boh[q] -= p.OH; ++bn[q]; }
+        }
+    };
+    auto store_tile = [&](int stage) {
+        unsigned char* as = smem + stage * STAGE;
+        unsigned char* bs = as + BKP * RB_A;
+#pragma unroll
+        for (int q = 0; q < PASS_A; ++q)
+            *reinterpret_cast<u32x4*>(as + (a_row0 + q * RPP_A) * RB_A + a_chunk * 16) = av[q];
+#pragma unroll
+        for (int q = 0; q < PASS_B; ++q)
+            *reinterpret_cast<u32x4*>(bs + (b_row0 + q * RPP_B) * RB_B + b_chunk * 16) = bv[q];
+    };
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = pix_end > pix_begin ? (pix_end - pix_begin + BKP - 1) / BKP : 0;
+    if (nkt > 0) {
+        load_tile(pix_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int q16 = lane & 15, g = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(pix_begin + (kt + 1) * BKP);
+        const unsigned char* as = smem + cur * STAGE;
+        const unsigned char* bs = as + BKP * RB_A;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < BKP / 32; ++kk) {
+                f16x8 a[TI], b[TJ];
+                if constexpr (USE_TR) {
+                    // lane supplies row (q16>>2) and 4 channels at (q16&3)*4 of a [4 pixel][16 channel] block;
+                    // it receives channel q16 of the 4 pixel rows (hardware transpose within 16 lanes).
+                    const int prow = kk * 32 + g * 8 + (q16 >> 2);
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) {
+                        const unsigned char* ptr = as + prow * RB_A + ((wi * (BCO / 2) + i * 16 + ((q16 & 3) << 2)) << 1);
+                        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_t*)(ptr));
+                        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_t*)(ptr + 4 * RB_A));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[i][e] = (f16)lo[e]; a[i][4 + e] = (f16)hi[e]; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        const unsigned char* ptr = bs + prow * RB_B + ((wj * (BCI / 2) + j * 16 + ((q16 & 3) << 2)) << 1);
+                        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_t*)(ptr));
+                        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) fp16x4_t*)(ptr + 4 * RB_B));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { b[j][e] = (f16)lo[e]; b[j][4 + e] = (f16)hi[e]; }
+                    }
+                } else {
+                    const int prow = kk * 32 + g * 8;
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            a[i][e] = *reinterpret_cast<const f16*>(as + (prow + e) * RB_A + ((wi * (BCO / 2) + i * 16 + q16) << 1));
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            b[j][e] = *reinterpret_cast<const f16*>(bs + (prow + e) * RB_B + ((wj * (BCI / 2) + j * 16 + q16) << 1));
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BKP / 4; ++kk) {
+                float a[TI], b[TJ];
+                const int prow = kk * 4 + g;
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+                    a[i] = *reinterpret_cast<const float*>(as + prow * RB_A + ((wi * (BCO / 2) + i * 16 + q16) << 2));
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    b[j] = *reinterpret_cast<const float*>(bs + prow * RB_B + ((wj * (BCI / 2) + j * 16 + q16) << 2));
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // D[co = ... + g*4 + r][col = ... + q16]
+    float* slab = p.part + (size_t)sp * p.CoRows * p.Ncols;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = col0 + wj * (BCI / 2) + j * 16 + q16;
+            if (col >= p.Ncols) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wi * (BCO / 2) + i * 16 + g * 4 + r;
+                if (co < p.CoRows) slab[(size_t)co * p.Ncols + col] = acc[i][j][r];
+            }
+        }
+}
+
+template <typename T, int BCO, int BCI, bool USE_TR>
+int launch(const WgradParams& p, int split, hipStream_t s) {
+    constexpr int BKP = WTraits<T>::BKP;
+    constexpr int smem = 2 * BKP * (BCO * (int)sizeof(T) + 32 + BCI * (int)sizeof(T) + 32);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, USE_TR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    dim3 grid((p.Ncols + BCI - 1) / BCI, (p.CoRows + BCO - 1) / BCO, split);
+    hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI, USE_TR>), grid, dim3(256), smem, s, p);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+inline int tile_of(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
+
+template <typename T, bool USE_TR>
+int dispatch(const WgradParams& p, int split, hipStream_t s) {
+    const int bco = tile_of(p.CoRows), bci = tile_of(p.Ncols);
+#define CY_W(A, B) \
+    if (bco == A && bci == B) return launch<T, A, B, USE_TR>(p, split, s);
+    CY_W(128, 128) CY_W(128, 64) CY_W(128, 32) CY_W(64, 128) CY_W(64, 64) CY_W(64, 32) CY_W(32, 128) CY_W(32, 64)
+    CY_W(32, 32)
+#undef CY_W
+    return CY_ERR_ARG;
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int split, int CoRows, int CiPad, int ks, int Co,
+                                    int Ci, float scale, int accumulate, float* __restrict__ grad) {
+    const int total = Co * Ci * ks * ks;
+    const int ncols = ks * ks * CiPad;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        // idx walks the slab-friendly order (co, tap, ci) so that reads are coalesced
+        const int ci = idx % Ci;
+        const int t = idx / Ci;
+        const int tap = t % (ks * ks), co = t / (ks * ks);
+        const size_t src = (size_t)co * ncols + tap * CiPad + ci;
+        float s = 0.f;
+        for (int sp = 0; sp < split; ++sp) s += part[(size_t)sp * CoRows * ncols + src];
+        const size_t dst = ((size_t)co * Ci + ci) * ks * ks + tap;
+        grad[dst] = scale * s + (accumulate ? grad[dst] : 0.f);
+    }
+}
+
+__global__ void probe_tr16_kernel(uint16_t* out) {
+    __shared__ __attribute__((aligned(16))) uint16_t tile[16 * 16];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) tile[i] = (uint16_t)i;
+    __syncthreads();
+    const int q = lane & 15, g = lane >> 4;
+    const uint16_t* ptr = tile + (g * 4 + (q >> 2)) * 16 + ((q & 3) << 2);
+    const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr));
+    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+    const u16x4 u = __builtin_bit_cast(u16x4, v);
+    for (int e = 0; e < 4; ++e) out[lane * 4 + e] = u[e];
+}
+
+}  // namespace
+
+extern "C" int cy_conv_wgrad_split(int M, int Co, int Ci, int ks) {
+    const int ncols = ks * ks * Ci;
+    const long tiles = (long)((Co + tile_of(Co) - 1) / tile_of(Co)) * ((ncols + tile_of(ncols) - 1) / tile_of(ncols));
+    long split = (1024 + tiles - 1) / tiles;
+    const long max_by_work = (M + 255) / 256;  // at least 4 K steps per block
+    if (split > max_by_work) split = max_by_work;
+    const long slab = (long)Co * ncols * 4;
+    while (split > 1 && split * slab > (256L << 20)) --split;
+    return (int)(split < 1 ? 1 : split);
+}
+
+extern "C" int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int lddy, const void* x, int XH, int XW,
+                             int Ci, int ldx, int ks, int stride, int pad, int dtype, float* part, int split,
+                             int use_tr, cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!dy || !x || !part || split < 1 || (dtype != CY_F16 && dtype != CY_F32)) return CY_ERR_ARG;
+    if (Co % ch || Ci % ch || lddy % ch || ldx % ch || ks < 1 || ks > 3) return CY_ERR_ARG;
+    WgradParams p;
+    p.dy = (const unsigned char*)dy; p.x = (const unsigned char*)x; p.part = part;
+    p.N = N; p.OH = OH; p.OW = OW; p.Co = Co; p.lddy = lddy;
+    p.XH = XH; p.XW = XW; p.Ci = Ci; p.ldx = ldx; p.ks = ks; p.stride = stride; p.pad = pad;
+    p.M = N * OH * OW; p.Ncols = ks * ks * Ci; p.CoRows = Co;
+    const int bkp = dtype == CY_F16 ? 64 : 32;
+    p.pps = (((p.M + split - 1) / split) + bkp - 1) / bkp * bkp;
+    if (dtype == CY_F32) return dispatch<float, false>(p, split, cy_s(s));
+    return use_tr ? dispatch<f16, true>(p, split, cy_s(s)) : dispatch<f16, false>(p, split, cy_s(s));
+}
+
+extern "C" int cy_wgrad_reduce(const float* part, int split, int CoRows, int CiPad, int ks, int Co, int Ci, float scale,
+                               int accumulate, float* grad, cy_stream_t s) {
+    if (!part || !grad || split < 1 || Co > CoRows || Ci > CiPad) return CY_ERR_ARG;
+    const int total = Co * Ci * ks * ks;
+    const int blocks = min(2048, (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, cy_s(s), part, split, CoRows, CiPad, ks, Co, Ci,
+                       scale, accumulate, grad);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_probe_tr16(uint16_t* out, cy_stream_t s) {
+    if (!out) return CY_ERR_ARG;
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, cy_s(s), out);
+    CY_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,631 @@
+// HBM-bound passes of the conv stack: BatchNorm statistics / apply / backward, activations, shortcut,
+// max-pool, nearest upsample, channel-slice copies, layout packing.  All NHWC views, 16-byte chunks
+// per lane, per-channel parameters held in registers (a thread always works on the same channel chunk).
+#include "common.hpp"
+
+namespace {
+
+// A block walks pixels [blockIdx*ppb, ...) ; thread = (row = tid / cpr, chunk = tid % cpr).
+// cpr = C / CH must divide 256 (true for every BN layer: C in {32..1024}, f16/f32).
+struct RowMap {
+    int cpr, rpp;  // chunks per row, rows per pass
+};
+
+template <typename T, int ACT, bool RES>
+__global__ void __launch_bounds__(256) bn_act_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                        const T* __restrict__ res, int ldres, long M, int C,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int ppb) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH, rpp = 256 / cpr;
+    const int chunk = threadIdx.x % cpr, row = threadIdx.x / cpr;
+    float sc[CH], sh[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { sc[i] = scale[chunk * CH + i]; sh[i] = shift[chunk * CH + i]; }
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < M ? p0 + ppb : M;
+    for (long p = p0 + row; p < p1; p += rpp) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + p * ldx + chunk * CH);
+        float f[CH];
+        chunk_to_f32<T>(v, f);
+        float r[CH];
+        if (RES) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(res + p * ldres + chunk * CH);
+            chunk_to_f32<T>(rv, r);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            f[i] = act_f<ACT>(f[i] * sc[i] + sh[i]);
+            if (RES) f[i] += r[i];
+        }
+        *reinterpret_cast<u32x4*>(y + p * ldy + chunk * CH) = f32_to_chunk<T>(f);
+    }
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy,
+                                                           int lddy, long M, int C, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int ppb,
+                                                           float* __restrict__ part) {
+    constexpr int CH = Elem<T>::CH;
+    __shared__ float red[256 * CH * 2];
+    const int cpr = C / CH, rpp = 256 / cpr;
+    const int chunk = threadIdx.x % cpr, row = threadIdx.x / cpr;
+    float sc[CH], sh[CH], mu[CH], is[CH], s1[CH], s2[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = chunk * CH + i;
+        sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c]; is[i] = invstd[c];
+        s1[i] = 0.f; s2[i] = 0.f;
+    }
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < M ? p0 + ppb : M;
+    for (long p = p0 + row; p < p1; p += rpp) {
+        float f[CH], g[CH];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(x + p * ldx + chunk * CH), f);
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(dy + p * lddy + chunk * CH), g);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const float dz = g[i] * act_grad<ACT>(f[i] * sc[i] + sh[i]);
+            s1[i] += dz;
+            s2[i] += dz * (f[i] - mu[i]) * is[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        red[(threadIdx.x * 2 + 0) * CH + i] = s1[i];
+        red[(threadIdx.x * 2 + 1) * CH + i] = s2[i];
+    }
+    __syncthreads();
+    // thread t < cpr*CH*2 sums column (chunk, which, i) over the rpp rows
+    for (int o = threadIdx.x; o < cpr * CH * 2; o += 256) {
+        const int i = o % CH, which = (o / CH) & 1, ck = o / (2 * CH);
+        float s = 0.f;
+        for (int r = 0; r < rpp; ++r) s += red[((r * cpr + ck) * 2 + which) * CH + i];
+        part[((size_t)blockIdx.x * 2 + which) * C + ck * CH + i] = s;
+    }
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ x, int ldx, const T* dy, int lddy,
+                                                          T* dx, int lddx, T* resg, int ldrg, int res_accum, long M,
+                                                          int C, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ dgs,
+                                                          const float* __restrict__ dbs, int ppb) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH, rpp = 256 / cpr;
+    const int chunk = threadIdx.x % cpr, row = threadIdx.x / cpr;
+    const float invM = 1.f / (float)M;
+    float sc[CH], sh[CH], mu[CH], is[CH], mg[CH], mb[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = chunk * CH + i;
+        sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c]; is[i] = invstd[c];
+        mg[i] = dgs[c] * invM; mb[i] = dbs[c] * invM;
+    }
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < M ? p0 + ppb : M;
+    for (long p = p0 + row; p < p1; p += rpp) {
+        float f[CH], g[CH];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(x + p * ldx + chunk * CH), f);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + p * lddy + chunk * CH);
+        chunk_to_f32<T>(gv, g);
+        if (resg) {
+            if (res_accum) {
+                float o[CH];
+                chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(resg + p * ldrg + chunk * CH), o);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) o[i] += g[i];
+                *reinterpret_cast<u32x4*>(resg + p * ldrg + chunk * CH) = f32_to_chunk<T>(o);
+            } else {
+                *reinterpret_cast<u32x4*>(resg + p * ldrg + chunk * CH) = gv;
+            }
+        }
+        float o[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const float dz = g[i] * act_grad<ACT>(f[i] * sc[i] + sh[i]);
+            const float xh = (f[i] - mu[i]) * is[i];
+            o[i] = sc[i] * (dz - mb[i] - xh * mg[i]);
+        }
+        *reinterpret_cast<u32x4*>(dx + p * lddx + chunk * CH) = f32_to_chunk<T>(o);
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* rmean,
+                                   float* rvar, long long* nbt, float momentum, float eps, float* mean, float* invstd,
+                                   float* scale, float* shift) {
+    // one wave per channel: lanes stride over the partial rows, accumulate in double
+    const int c = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = lane; r < rows; r += 64) {
+        s += (double)part[((size_t)r * 2) * C + c];
+        q += (double)part[((size_t)r * 2 + 1) * C + c];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane == 0) {
+        const double m = s / count;
+        double var = q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = (float)m;
+        invstd[c] = is;
+        const float sc = gamma[c] * is;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)m * sc;
+        if (rmean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+        if (nbt && c == 0) *nbt += 1;
+    }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, int C,
+                                      float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, float* dgs, float* dbs,
+                                       float* ggamma, float* gbeta, float gscale) {
+    const int c = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = lane; r < rows; r += 64) {
+        s1 += (double)part[((size_t)r * 2) * C + c];
+        s2 += (double)part[((size_t)r * 2 + 1) * C + c];
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane == 0) {
+        dbs[c] = (float)s1;
+        dgs[c] = (float)s2;
+        if (gbeta) gbeta[c] += gscale * (float)s1;
+        if (ggamma) ggamma[c] += gscale * (float)s2;
+    }
+}
+
+// ---- generic chunked element kernels (any C multiple of CH) ------------------------------------
+template <typename T, int MODE>  // 0: y = x, 1: y += x, 2: y = a + b (x = a, z = b)
+__global__ void slice_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ z, int ldz, T* y, int ldy, long M,
+                             int C) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH;
+    const long total = M * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / cpr;
+        const int ck = (int)(i - p * cpr);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + p * ldx + ck * CH);
+        if (MODE == 0) {
+            *reinterpret_cast<u32x4*>(y + p * ldy + ck * CH) = v;
+        } else {
+            float a[CH], b[CH];
+            chunk_to_f32<T>(v, a);
+            if (MODE == 1) chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(y + p * ldy + ck * CH), b);
+            else chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(z + p * ldz + ck * CH), b);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) a[e] += b[e];
+            *reinterpret_cast<u32x4*>(y + p * ldy + ck * CH) = f32_to_chunk<T>(a);
+        }
+    }
+}
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int ldx, T* __restrict__ y,
+                                   int OH, int OW, int ldy, int k, int stride, int pad, uint8_t* __restrict__ amax) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH;
+    const long total = (long)N * OH * OW * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / cpr;
+        const int ck = (int)(i - p * cpr);
+        const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), n = (int)(p / ((long)OW * OH));
+        float best[CH];
+        int arg[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+        for (int a = 0; a < k; ++a) {
+            const int h = oh * stride - pad + a;
+            if (h < 0 || h >= H) continue;
+            for (int b = 0; b < k; ++b) {
+                const int w = ow * stride - pad + b;
+                if (w < 0 || w >= W) continue;
+                float f[CH];
+                chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(x + ((long)(n * H + h) * W + w) * ldx + ck * CH), f);
+#pragma unroll
+                for (int e = 0; e < CH; ++e)
+                    if (f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; arg[e] = a * k + b; }
+            }
+        }
+        *reinterpret_cast<u32x4*>(y + p * ldy + ck * CH) = f32_to_chunk<T>(best);
+        if (amax) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) amax[p * C + ck * CH + e] = (uint8_t)arg[e];
+        }
+    }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_scatter_kernel(const T* __restrict__ dy, int N, int OH, int OW, int C, int lddy,
+                                           const uint8_t* __restrict__ amax, float* __restrict__ scratch, int H, int W,
+                                           int k, int stride, int pad) {
+    const long total = (long)N * OH * OW * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / C;
+        const int c = (int)(i - p * C);
+        const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), n = (int)(p / ((long)OW * OH));
+        const int a = amax[i] / k, b = amax[i] % k;
+        const int h = oh * stride - pad + a, w = ow * stride - pad + b;
+        atomicAdd(scratch + ((long)(n * H + h) * W + w) * C + c, (float)dy[p * lddy + c]);
+    }
+}
+
+template <typename T>
+__global__ void f32_to_view_kernel(const float* __restrict__ x, long M, int C, float scale, T* __restrict__ y, int ldy,
+                                   int CPad, int accumulate) {
+    const long total = M * CPad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / CPad;
+        const int c = (int)(i - p * CPad);
+        float v = c < C ? x[p * C + c] * scale : 0.f;
+        if (accumulate) v += (float)y[p * ldy + c];
+        y[p * ldy + c] = (T)v;
+    }
+}
+
+template <typename T>
+__global__ void upsample_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int ldx, T* __restrict__ y,
+                                    int ldy, int st) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH, OH = H * st, OW = W * st;
+    const long total = (long)N * OH * OW * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / cpr;
+        const int ck = (int)(i - p * cpr);
+        const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), n = (int)(p / ((long)OW * OH));
+        *reinterpret_cast<u32x4*>(y + p * ldy + ck * CH) =
+            *reinterpret_cast<const u32x4*>(x + ((long)(n * H + oh / st) * W + ow / st) * ldx + ck * CH);
+    }
+}
+
+template <typename T>
+__global__ void upsample_bwd_kernel(const T* __restrict__ dy, int N, int H, int W, int C, int lddy, T* dx, int lddx,
+                                    int st, int accumulate) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH, OW = W * st;
+    const long total = (long)N * H * W * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / cpr;
+        const int ck = (int)(i - p * cpr);
+        const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((long)W * H));
+        float s[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) s[e] = 0.f;
+        if (accumulate) chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(dx + p * lddx + ck * CH), s);
+        for (int a = 0; a < st; ++a)
+            for (int b = 0; b < st; ++b) {
+                float f[CH];
+                const long q = ((long)(n * H * st + h * st + a)) * OW + w * st + b;
+                chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(dy + q * lddy + ck * CH), f);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) s[e] += f[e];
+            }
+        *reinterpret_cast<u32x4*>(dx + p * lddx + ck * CH) = f32_to_chunk<T>(s);
+    }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int N, int C, int H, int W, int CPad,
+                                    T* __restrict__ y) {
+    const long total = (long)N * H * W;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const long hw = (long)H * W;
+        const long n = p / hw, r = p - n * hw;
+        for (int c = 0; c < CPad; ++c) y[p * CPad + c] = c < C ? (T)x[(n * C + c) * hw + r] : (T)0.f;
+    }
+}
+
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, int Co, int Ci, int ks, int CoPad, int CiPad,
+                                    T* __restrict__ wf, T* __restrict__ wd) {
+    const int kk = ks * ks;
+    const long total = (long)CoPad * kk * CiPad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % CiPad);
+        const int tap = (int)((i / CiPad) % kk);
+        const int co = (int)(i / ((long)CiPad * kk));
+        const float v = (co < Co && ci < Ci) ? w[((long)co * Ci + ci) * kk + tap] : 0.f;
+        wf[i] = (T)v;
+        if (wd) wd[((long)ci * kk + tap) * CoPad + co] = (T)v;
+    }
+}
+
+__global__ void bias_grad_kernel(const float* __restrict__ d, long M, int C, float scale, float* gbias) {
+    // block b handles channel b: strided sum over pixels
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (long p = threadIdx.x; p < M; p += blockDim.x) s += (double)d[p * C + c];
+    __shared__ double red[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) gbias[c] += scale * (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+inline int grid_for(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+inline bool rowmap_ok(int C, int ch) {
+    const int cpr = C / ch;
+    return C % ch == 0 && cpr >= 1 && cpr <= 256 && (256 % cpr) == 0;
+}
+
+inline int ppb_for(long M, int C, int ch) {
+    // pixels per block: aim at ~2048 blocks, at least 4 passes per thread row
+    const int rpp = 256 / (C / ch);
+    long ppb = (M + 2047) / 2048;
+    if (ppb < 4L * rpp) ppb = 4L * rpp;
+    ppb = (ppb + rpp - 1) / rpp * rpp;
+    return (int)ppb;
+}
+
+}  // namespace
+
+#define CY_DT_SWITCH(dtype, EXPR_F16, EXPR_F32) \
+    if (dtype == CY_F16) { EXPR_F16; } else if (dtype == CY_F32) { EXPR_F32; } else return CY_ERR_ARG;
+
+extern "C" int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
+                             const float* scale, const float* shift, int act, int dtype, cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!x || !y || !scale || !shift || !rowmap_ok(C, ch) || ldx % ch || ldy % ch || (res && ldres % ch)) return CY_ERR_ARG;
+    const int ppb = ppb_for(M, C, ch);
+    const dim3 grid((unsigned)((M + ppb - 1) / ppb));
+#define CY_BNF(T, A)                                                                                               \
+    if (res) hipLaunchKernelGGL((bn_act_fwd_kernel<T, A, true>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (T*)y, \
+                                ldy, (const T*)res, ldres, (long)M, C, scale, shift, ppb);                         \
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<T, A, false>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (T*)y,   \
+                            ldy, (const T*)nullptr, 0, (long)M, C, scale, shift, ppb);
+#define CY_BNF_ACT(T)                                        \
+    if (act == CY_ACT_MISH) { CY_BNF(T, CY_ACT_MISH) }       \
+    else if (act == CY_ACT_LEAKY) { CY_BNF(T, CY_ACT_LEAKY) } \
+    else { CY_BNF(T, CY_ACT_LINEAR) }
+    CY_DT_SWITCH(dtype, CY_BNF_ACT(f16), CY_BNF_ACT(float))
+#undef CY_BNF
+#undef CY_BNF_ACT
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_bn_bwd_rows(int64_t M, int C, int dtype) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!rowmap_ok(C, ch)) return CY_ERR_ARG;
+    const int ppb = ppb_for(M, C, ch);
+    return (int)((M + ppb - 1) / ppb);
+}
+
+extern "C" int cy_bn_act_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, int64_t M, int C,
+                                    const float* mean, const float* invstd, const float* scale, const float* shift,
+                                    int act, int dtype, float* part, cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!x || !dy || !part || !rowmap_ok(C, ch) || ldx % ch || lddy % ch) return CY_ERR_ARG;
+    const int ppb = ppb_for(M, C, ch);
+    const dim3 grid((unsigned)((M + ppb - 1) / ppb));
+#define CY_BNR(T, A)                                                                                            \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, A>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (const T*)dy, \
+                       lddy, (long)M, C, mean, invstd, scale, shift, ppb, part);
+#define CY_BNR_ACT(T)                                        \
+    if (act == CY_ACT_MISH) { CY_BNR(T, CY_ACT_MISH) }       \
+    else if (act == CY_ACT_LEAKY) { CY_BNR(T, CY_ACT_LEAKY) } \
+    else { CY_BNR(T, CY_ACT_LINEAR) }
+    CY_DT_SWITCH(dtype, CY_BNR_ACT(f16), CY_BNR_ACT(float))
+#undef CY_BNR
+#undef CY_BNR_ACT
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_bn_act_bwd_apply(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx,
+                                   void* res_grad, int ldrg, int res_accum, int64_t M, int C, const float* mean,
+                                   const float* invstd, const float* scale, const float* shift,
+                                   const float* dgamma_sum, const float* dbeta_sum, int act, int dtype,
+                                   cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!x || !dy || !dx || !rowmap_ok(C, ch) || ldx % ch || lddy % ch || lddx % ch || (res_grad && ldrg % ch))
+        return CY_ERR_ARG;
+    const int ppb = ppb_for(M, C, ch);
+    const dim3 grid((unsigned)((M + ppb - 1) / ppb));
+#define CY_BNA(T, A)                                                                                           \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, A>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (const T*)dy, \
+                       lddy, (T*)dx, lddx, (T*)res_grad, ldrg, res_accum, (long)M, C, mean, invstd, scale, shift, \
+                       dgamma_sum, dbeta_sum, ppb);
+#define CY_BNA_ACT(T)                                        \
+    if (act == CY_ACT_MISH) { CY_BNA(T, CY_ACT_MISH) }       \
+    else if (act == CY_ACT_LEAKY) { CY_BNA(T, CY_ACT_LEAKY) } \
+    else { CY_BNA(T, CY_ACT_LINEAR) }
+    CY_DT_SWITCH(dtype, CY_BNA_ACT(f16), CY_BNA_ACT(float))
+#undef CY_BNA
+#undef CY_BNA_ACT
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_bn_finalize(const float* stats_part, int rows, int C, int64_t count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, float momentum, float eps, float* mean, float* invstd,
+                              float* scale, float* shift, cy_stream_t s) {
+    if (!stats_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows < 1 || count < 1)
+        return CY_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), stats_part, rows, C, (double)count,
+                       gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, mean,
+                       invstd, scale, shift);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, int C, float eps, float* scale, float* shift,
+                                 cy_stream_t s) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return CY_ERR_ARG;
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, cy_s(s), gamma, beta, running_mean,
+                       running_var, C, eps, scale, shift);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_bn_bwd_finalize(const float* part, int rows, int C, float* dgamma_sum, float* dbeta_sum,
+                                  float* ggamma, float* gbeta, float gscale, cy_stream_t s) {
+    if (!part || !dgamma_sum || !dbeta_sum || rows < 1) return CY_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), part, rows, C, dgamma_sum,
+                       dbeta_sum, ggamma, gbeta, gscale);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_slice_copy(const void* x, int ldx, void* y, int ldy, int64_t M, int C, int accumulate, int dtype,
+                             cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!x || !y || C % ch || ldx % ch || ldy % ch) return CY_ERR_ARG;
+    const int g = grid_for(M * (C / ch));
+#define CY_SL(T)                                                                                                     \
+    if (accumulate) hipLaunchKernelGGL((slice_kernel<T, 1>), dim3(g), dim3(256), 0, cy_s(s), (const T*)x, ldx,       \
+                                       (const T*)nullptr, 0, (T*)y, ldy, (long)M, C);                                \
+    else hipLaunchKernelGGL((slice_kernel<T, 0>), dim3(g), dim3(256), 0, cy_s(s), (const T*)x, ldx, (const T*)nullptr, \
+                            0, (T*)y, ldy, (long)M, C);
+    CY_DT_SWITCH(dtype, CY_SL(f16), CY_SL(float))
+#undef CY_SL
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_slice_add(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int64_t M, int C,
+                            int dtype, cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!a || !b || !y || C % ch || lda % ch || ldb % ch || ldy % ch) return CY_ERR_ARG;
+    const int g = grid_for(M * (C / ch));
+#define CY_SA(T) \
+    hipLaunchKernelGGL((slice_kernel<T, 2>), dim3(g), dim3(256), 0, cy_s(s), (const T*)a, lda, (const T*)b, ldb, (T*)y, \
+                       ldy, (long)M, C);
+    CY_DT_SWITCH(dtype, CY_SA(f16), CY_SA(float))
+#undef CY_SA
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_maxpool_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int OH, int OW, int ldy,
+                              int k, int stride, int pad, uint8_t* argmax, int dtype, cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!x || !y || C % ch || ldx % ch || ldy % ch || k < 1 || k > 15) return CY_ERR_ARG;
+    const int g = grid_for((long)N * OH * OW * (C / ch));
+#define CY_MP(T) \
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), (const T*)x, N, H, W, C, ldx, (T*)y, OH, \
+                       OW, ldy, k, stride, pad, argmax);
+    CY_DT_SWITCH(dtype, CY_MP(f16), CY_MP(float))
+#undef CY_MP
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int lddy, const uint8_t* argmax, void* dx,
+                              int H, int W, int lddx, int k, int stride, int pad, int accumulate, float* scratch,
+                              int dtype, cy_stream_t s) {
+    if (!dy || !argmax || !dx || !scratch) return CY_ERR_ARG;
+    const long in_elems = (long)N * H * W * C;
+    if (hipMemsetAsync(scratch, 0, in_elems * sizeof(float), cy_s(s)) != hipSuccess) return -(1000 + 1);
+    const int g = grid_for((long)N * OH * OW * C);
+    const int g2 = grid_for(in_elems);
+#define CY_MB(T)                                                                                                       \
+    hipLaunchKernelGGL((maxpool_bwd_scatter_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), (const T*)dy, N, OH, OW, C, lddy, \
+                       argmax, scratch, H, W, k, stride, pad);                                                         \
+    hipLaunchKernelGGL((f32_to_view_kernel<T>), dim3(g2), dim3(256), 0, cy_s(s), (const float*)scratch,                \
+                       (long)N * H * W, C, 1.f, (T*)dx, lddx, C, accumulate);
+    CY_DT_SWITCH(dtype, CY_MB(f16), CY_MB(float))
+#undef CY_MB
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_upsample_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, int stride,
+                               int dtype, cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!x || !y || C % ch || ldx % ch || ldy % ch || stride < 1) return CY_ERR_ARG;
+    const int g = grid_for((long)N * H * W * stride * stride * (C / ch));
+#define CY_UF(T) \
+    hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), (const T*)x, N, H, W, C, ldx, (T*)y, ldy, stride);
+    CY_DT_SWITCH(dtype, CY_UF(f16), CY_UF(float))
+#undef CY_UF
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_upsample_bwd(const void* dy, int N, int H, int W, int C, int lddy, void* dx, int lddx, int stride,
+                               int accumulate, int dtype, cy_stream_t s) {
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!dy || !dx || C % ch || lddy % ch || lddx % ch || stride < 1) return CY_ERR_ARG;
+    const int g = grid_for((long)N * H * W * (C / ch));
+#define CY_UB(T) \
+    hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), (const T*)dy, N, H, W, C, lddy, (T*)dx, lddx, stride, accumulate);
+    CY_DT_SWITCH(dtype, CY_UB(f16), CY_UB(float))
+#undef CY_UB
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_f32_to_view(const float* x, int64_t M, int C, float scale, void* y, int ldy, int CPad, int dtype,
+                              cy_stream_t s) {
+    if (!x || !y || CPad < C || ldy < CPad) return CY_ERR_ARG;
+    const int g = grid_for(M * CPad);
+#define CY_FV(T) \
+    hipLaunchKernelGGL((f32_to_view_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), x, (long)M, C, scale, (T*)y, ldy, CPad, 0);
+    CY_DT_SWITCH(dtype, CY_FV(f16), CY_FV(float))
+#undef CY_FV
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dtype, void* out,
+                               cy_stream_t s) {
+    if (!x || !out || CPad < C) return CY_ERR_ARG;
+    const int g = grid_for((long)N * H * W);
+#define CY_NH(T) \
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), x, N, C, H, W, CPad, (T*)out);
+    CY_DT_SWITCH(dtype, CY_NH(f16), CY_NH(float))
+#undef CY_NH
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad, int CiPad, int dtype, void* wf,
+                               void* wd, cy_stream_t s) {
+    if (!w || !wf || CoPad < Co || CiPad < Ci) return CY_ERR_ARG;
+    const int g = grid_for((long)CoPad * ks * ks * CiPad);
+#define CY_PW(T) \
+    hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), w, Co, Ci, ks, CoPad, CiPad, (T*)wf, (T*)wd);
+    CY_DT_SWITCH(dtype, CY_PW(f16), CY_PW(float))
+#undef CY_PW
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, float* gbias, cy_stream_t s) {
+    if (!dlogits || !gbias || C < 1) return CY_ERR_ARG;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, cy_s(s), dlogits, (long)M, C, scale, gbias);
+    CY_LAUNCH_CHECK();
+    return 0;
+}

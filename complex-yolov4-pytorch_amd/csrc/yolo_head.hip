@@ -1,0 +1,370 @@
+// YOLO head on device: decode, fused target assignment + loss + metrics + d(loss)/d(logits).
+// Reference: models/yolo_layer.py (decode :144-189, build_targets :69-142, loss/metrics :199-251).
+// Logits arrive NHWC fp32 straight from the head conv: [B][G][G][A*(7+C)], so one cell's A*(7+C)
+// values are contiguous.  Targets are few (nT ~ 100): assignment is sparse (one lane per target,
+// atomics for the per-cell ownership maps); only the objectness BCE and the metric counters are dense.
+// All sums accumulate in double atomics, so the value does not depend on a float32 reduction tree.
+#include "common.hpp"
+#include "geometry.hpp"
+
+namespace {
+
+constexpr int MAXA = 8;
+struct Anchors {
+    float w[MAXA], h[MAXA], im[MAXA], re[MAXA];  // w,h already divided by the stride (grid units)
+};
+
+enum Acc {
+    A_SX, A_SY, A_SW, A_SH, A_SIM, A_SRE, A_UNIT, A_BCE_OBJ, A_BCE_NOOBJ, A_CLS, A_GIOU, A_IOU, A_CLSACC,
+    A_CONF_OBJ, A_CONF_NOOBJ, A_CONF50, A_DET50, A_DET75, A_COUNT
+};
+enum Cnt { C_NOBJ, C_NCLEARED, C_ERR, C_COUNT };
+
+struct Work {
+    int* owner;     // [cells]  max(target index + 1) that claimed the cell
+    int* flags;     // [cells]  bit0: noobj cleared; bit (8+c): class c present
+    double* acc;    // [A_COUNT]
+    int* cnt;       // [C_COUNT]
+    int* ti;        // [nT][4]  b, best anchor, gj, gi  (b = -1: rejected)
+    float* tf;      // [nT][8]  iou, term, g[6]
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void decode_kernel(const float* __restrict__ logits, int B, int G, int A, int C, Anchors an, float stride,
+                              float* __restrict__ out, int rows_total, int row_offset) {
+    const int NCH = 7 + C;
+    const long total = (long)B * G * G * A;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(i % A);
+        const long cell = i / A;
+        const int gx = (int)(cell % G), gy = (int)((cell / G) % G), b = (int)(cell / ((long)G * G));
+        const float* t = logits + cell * (A * NCH) + a * NCH;
+        float* o = out + ((long)b * rows_total + row_offset + ((long)a * G + gy) * G + gx) * NCH;
+        o[0] = (sigmoidf_(t[0]) + (float)gx) * stride;
+        o[1] = (sigmoidf_(t[1]) + (float)gy) * stride;
+        o[2] = fminf(expf(t[2]), 1e3f) * an.w[a] * stride;
+        o[3] = fminf(expf(t[3]), 1e3f) * an.h[a] * stride;
+        o[4] = t[4];
+        o[5] = t[5];
+        for (int c = 6; c < NCH; ++c) o[c] = sigmoidf_(t[c]);
+    }
+}
+
+__global__ void assign_kernel(const float* __restrict__ targets, int nT, int B, int G, int A, Anchors an,
+                              float ignore_thresh, Work w) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nT) return;
+    const float* t = targets + (long)k * 8;
+    const int b = (int)t[0], label = (int)t[1];
+    const float gf = (float)G;
+    const float x = t[2] * gf, y = t[3] * gf, tw = t[4] * gf, tl = t[5] * gf;
+    const int gi = (int)x, gj = (int)y;
+    if (b < 0 || b >= B || gi < 0 || gi >= G || gj < 0 || gj >= G || label < 0 || label > 22) {
+        w.ti[k * 4] = -1;
+        atomicAdd(&w.cnt[C_ERR], 1);
+        return;
+    }
+    float tcx[4], tcy[4], acx[4], acy[4];
+    geom::corners(100.f, 100.f, tw, tl, atan2f(t[6], t[7]), tcx, tcy);
+    const float tarea = tw * tl;
+    float best_iou = -1.f;
+    int best = 0;
+    float ious[MAXA];
+    for (int a = 0; a < A; ++a) {
+        geom::corners(100.f, 100.f, an.w[a], an.h[a], atan2f(an.im[a], an.re[a]), acx, acy);
+        const double inter = geom::quad_inter_f64(acx, acy, tcx, tcy);
+        ious[a] = geom::iou_from_inter(inter, an.w[a] * an.h[a], tarea, 1e-16f);
+        if (ious[a] > best_iou) { best_iou = ious[a]; best = a; }
+    }
+    w.ti[k * 4 + 0] = b; w.ti[k * 4 + 1] = best; w.ti[k * 4 + 2] = gj; w.ti[k * 4 + 3] = gi;
+    for (int a = 0; a < A; ++a) {
+        if (a != best && !(ious[a] > ignore_thresh)) continue;
+        const int cell = ((b * A + a) * G + gj) * G + gi;
+        const int old = atomicOr(&w.flags[cell], 1);
+        if (!(old & 1)) atomicAdd(&w.cnt[C_NCLEARED], 1);
+    }
+    const int cell = ((b * A + best) * G + gj) * G + gi;
+    atomicOr(&w.flags[cell], 1 << (8 + label));
+    const int old = atomicMax(&w.owner[cell], k + 1);
+    if (old == 0) atomicAdd(&w.cnt[C_NOBJ], 1);
+}
+
+__device__ __forceinline__ void decode_box(const float* t, int gi, int gj, float aw, float ah, float* box) {
+    box[0] = sigmoidf_(t[0]) + (float)gi;
+    box[1] = sigmoidf_(t[1]) + (float)gj;
+    box[2] = fminf(expf(t[2]), 1e3f) * aw;
+    box[3] = fminf(expf(t[3]), 1e3f) * ah;
+    box[4] = t[4];
+    box[5] = t[5];
+}
+
+__global__ void pairs_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT, int G, int A,
+                             int C, Anchors an, int use_giou, Work w) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nT) return;
+    const int b = w.ti[k * 4];
+    float* tf = w.tf + (long)k * 8;
+    if (b < 0) {
+        for (int i = 0; i < 8; ++i) tf[i] = 0.f;
+        return;
+    }
+    const int a = w.ti[k * 4 + 1], gj = w.ti[k * 4 + 2], gi = w.ti[k * 4 + 3];
+    const int NCH = 7 + C;
+    const float* lg = logits + ((long)(b * G + gj) * G + gi) * (A * NCH) + a * NCH;
+    float pb[6], tb[6];
+    decode_box(lg, gi, gj, an.w[a], an.h[a], pb);
+    const float* t = targets + (long)k * 8;
+    const float gf = (float)G;
+    tb[0] = t[2] * gf; tb[1] = t[3] * gf; tb[2] = t[4] * gf; tb[3] = t[5] * gf; tb[4] = t[6]; tb[5] = t[7];
+    const geom::PairOut o = geom::pair_term(pb, tb, use_giou != 0);
+    tf[0] = o.iou;
+    tf[1] = o.term;
+    for (int i = 0; i < 6; ++i) tf[2 + i] = o.g[i];
+    atomicAdd(&w.acc[A_GIOU], (double)o.term);
+}
+
+__device__ __forceinline__ float bce_grad(float p, float t) {
+    // d BCE / d p as torch computes it: (p - t) / max((1-p)*p, 1e-12)
+    return (p - t) / fmaxf((1.f - p) * p, 1e-12f);
+}
+
+struct Scales {
+    float gx, gy, gw, gh, geul, gobj, gnoobj, gcls;  // d total / d (mean terms)
+};
+
+__global__ void __launch_bounds__(256) dense_kernel(const float* __restrict__ logits, const float* __restrict__ targets,
+                                                    int B, int G, int A, int C, Anchors an, Scales sc, Work w,
+                                                    float* __restrict__ dlogits) {
+    const int NCH = 7 + C;
+    const long cells = (long)B * A * G * G;
+    const float nObj = (float)w.cnt[C_NOBJ];
+    const float nNoobj = (float)(cells - w.cnt[C_NCLEARED]);
+    double acc[A_COUNT];
+#pragma unroll
+    for (int i = 0; i < A_COUNT; ++i) acc[i] = 0.0;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (long)gridDim.x * blockDim.x) {
+        // idx enumerates (b, gj, gi, a) so that consecutive lanes read consecutive logits
+        const int a = (int)(idx % A);
+        const long pos = idx / A;
+        const int gi = (int)(pos % G), gj = (int)((pos / G) % G), b = (int)(pos / ((long)G * G));
+        const int cell = ((b * A + a) * G + gj) * G + gi;
+        const float* t = logits + pos * (A * NCH) + a * NCH;
+        float* d = dlogits + pos * (A * NCH) + a * NCH;
+        const int own = w.owner[cell], fl = w.flags[cell];
+        const float pc = sigmoidf_(t[6]);
+        const float conf50 = pc > 0.5f ? 1.f : 0.f;
+        acc[A_CONF50] += conf50;
+        float g[32];
+        for (int c = 0; c < NCH; ++c) g[c] = 0.f;
+        if (!(fl & 1)) {
+            acc[A_BCE_NOOBJ] += -fmaxf(log1pf(-pc), -100.f);
+            acc[A_CONF_NOOBJ] += pc;
+            g[6] = sc.gnoobj / nNoobj * bce_grad(pc, 0.f) * pc * (1.f - pc);
+        }
+        if (own > 0) {
+            const int k = own - 1;
+            const float* tg = targets + (long)k * 8;
+            const float gf = (float)G;
+            const float x = tg[2] * gf, y = tg[3] * gf, tw_ = tg[4] * gf, tl_ = tg[5] * gf;
+            const float tx = x - floorf(x), ty = y - floorf(y);
+            const float twl = logf(tw_ / an.w[a] + 1e-16f), thl = logf(tl_ / an.h[a] + 1e-16f);
+            const float sx = sigmoidf_(t[0]), sy = sigmoidf_(t[1]);
+            const float ex = sx - tx, ey = sy - ty, ew = t[2] - twl, eh = t[3] - thl;
+            const float eim = t[4] - tg[6], ere = t[5] - tg[7];
+            const float r = sqrtf(t[4] * t[4] + t[5] * t[5]);
+            acc[A_SX] += ex * ex; acc[A_SY] += ey * ey; acc[A_SW] += ew * ew; acc[A_SH] += eh * eh;
+            acc[A_SIM] += eim * eim; acc[A_SRE] += ere * ere;
+            acc[A_UNIT] += (1.f - r) * (1.f - r);
+            acc[A_BCE_OBJ] += -fmaxf(logf(pc), -100.f);
+            acc[A_CONF_OBJ] += pc;
+            g[0] = sc.gx / nObj * 2.f * ex * sx * (1.f - sx);
+            g[1] = sc.gy / nObj * 2.f * ey * sy * (1.f - sy);
+            g[2] = sc.gw / nObj * 2.f * ew;
+            g[3] = sc.gh / nObj * 2.f * eh;
+            const float du = -2.f * (1.f - r) / r;
+            g[4] = sc.geul / nObj * (2.f * eim + du * t[4]);
+            g[5] = sc.geul / nObj * (2.f * ere + du * t[5]);
+            g[6] += sc.gobj / nObj * bce_grad(pc, 1.f) * pc * (1.f - pc);
+            int arg = 0;
+            float bestc = -1.f;
+            for (int c = 0; c < C; ++c) {
+                const float p = sigmoidf_(t[7 + c]);
+                const float tc = (fl >> (8 + c)) & 1 ? 1.f : 0.f;
+                acc[A_CLS] += -(tc * fmaxf(logf(p), -100.f) + (1.f - tc) * fmaxf(log1pf(-p), -100.f));
+                g[7 + c] = sc.gcls / (nObj * (float)C) * bce_grad(p, tc) * p * (1.f - p);
+                if (p > bestc) { bestc = p; arg = c; }
+            }
+            const float cmask = (arg == (int)tg[1]) ? 1.f : 0.f;
+            const float iou = w.tf[(long)k * 8];
+            const float det = conf50 * cmask;
+            acc[A_IOU] += iou;
+            acc[A_CLSACC] += cmask;
+            acc[A_DET50] += (iou > 0.5f ? 1.f : 0.f) * det;
+            acc[A_DET75] += (iou > 0.75f ? 1.f : 0.f) * det;
+        }
+        for (int c = 0; c < NCH; ++c) d[c] = g[c];
+    }
+    __shared__ double red[4][A_COUNT];
+#pragma unroll
+    for (int i = 0; i < A_COUNT; ++i) {
+        if (i == A_GIOU) continue;
+        const double v = wave_sum_d(acc[i]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < A_COUNT && threadIdx.x != A_GIOU) {
+        const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (v != 0.0) atomicAdd(&w.acc[threadIdx.x], v);
+    }
+}
+
+__global__ void giou_grad_kernel(const float* __restrict__ logits, int nT, int G, int A, int C, Anchors an, float coef,
+                                 Work w, float* dlogits) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nT) return;
+    const int b = w.ti[k * 4];
+    if (b < 0) return;
+    const int a = w.ti[k * 4 + 1], gj = w.ti[k * 4 + 2], gi = w.ti[k * 4 + 3];
+    const int NCH = 7 + C;
+    const long base = ((long)(b * G + gj) * G + gi) * (A * NCH) + a * NCH;
+    const float* t = logits + base;
+    const float* g = w.tf + (long)k * 8 + 2;
+    const float sx = sigmoidf_(t[0]), sy = sigmoidf_(t[1]);
+    const float e2 = expf(t[2]), e3 = expf(t[3]);
+    atomicAdd(dlogits + base + 0, coef * g[0] * sx * (1.f - sx));
+    atomicAdd(dlogits + base + 1, coef * g[1] * sy * (1.f - sy));
+    atomicAdd(dlogits + base + 2, e2 <= 1e3f ? coef * g[2] * e2 * an.w[a] : 0.f);
+    atomicAdd(dlogits + base + 3, e3 <= 1e3f ? coef * g[3] * e3 * an.h[a] : 0.f);
+    atomicAdd(dlogits + base + 4, coef * g[4]);
+    atomicAdd(dlogits + base + 5, coef * g[5]);
+}
+
+struct LossScales {
+    float noobj, obj, lgiou, leular, lobj, lcls;
+};
+
+__global__ void finalize_kernel(Work w, long cells, int nT, int C, int use_giou, LossScales ls, float* metrics) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double nObj = (double)w.cnt[C_NOBJ];
+    const double nNo = (double)(cells - w.cnt[C_NCLEARED]);
+    const double* a = w.acc;
+    const float lx = (float)(a[A_SX] / nObj), ly = (float)(a[A_SY] / nObj);
+    const float lw = (float)(a[A_SW] / nObj), lh = (float)(a[A_SH] / nObj);
+    const float lim = (float)(a[A_SIM] / nObj), lre = (float)(a[A_SRE] / nObj);
+    const float leul = lim + lre + (float)(a[A_UNIT] / nObj);
+    const float co = (float)(a[A_BCE_OBJ] / nObj), cn = (float)(a[A_BCE_NOOBJ] / nNo);
+    const float lcls = (float)(a[A_CLS] / (nObj * (double)C));
+    const float giou = nT > 0 ? (float)(a[A_GIOU] / (double)nT) : 0.f;
+    float lobj, total;
+    if (use_giou) {
+        lobj = co + cn;
+        total = giou * ls.lgiou + leul * ls.leular + lobj * ls.lobj + lcls * ls.lcls;
+    } else {
+        lobj = ls.obj * co + ls.noobj * cn;
+        total = lx + ly + lw + lh + leul + lobj + lcls;
+    }
+    metrics[0] = total;
+    metrics[1] = (float)(a[A_IOU] / nObj);
+    metrics[2] = giou;
+    metrics[3] = lx; metrics[4] = ly; metrics[5] = lw; metrics[6] = lh;
+    metrics[7] = leul; metrics[8] = lim; metrics[9] = lre;
+    metrics[10] = lobj; metrics[11] = lcls;
+    metrics[12] = (float)(100.0 * a[A_CLSACC] / nObj);
+    metrics[13] = (float)(a[A_DET50] / (nObj + 1e-16));
+    metrics[14] = (float)(a[A_DET75] / (nObj + 1e-16));
+    metrics[15] = (float)(a[A_DET50] / (a[A_CONF50] + 1e-16));
+    metrics[16] = (float)(a[A_CONF_OBJ] / nObj);
+    metrics[17] = (float)(a[A_CONF_NOOBJ] / nNo);
+    metrics[18] = (float)nObj;
+    metrics[19] = (float)w.cnt[C_ERR];
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline Work carve(void* ws, long cells, int nT, size_t* zero_bytes, size_t* total_bytes = nullptr) {
+    unsigned char* p = (unsigned char*)ws;
+    Work w;
+    size_t off = 0;
+    w.acc = (double*)(p + off); off += align_up(sizeof(double) * A_COUNT, 256);
+    w.cnt = (int*)(p + off); off += 256;
+    w.owner = (int*)(p + off); off += align_up(sizeof(int) * cells, 256);
+    w.flags = (int*)(p + off); off += align_up(sizeof(int) * cells, 256);
+    if (zero_bytes) *zero_bytes = off;
+    w.ti = (int*)(p + off); off += align_up(sizeof(int) * 4 * (size_t)(nT > 0 ? nT : 1), 256);
+    w.tf = (float*)(p + off); off += align_up(sizeof(float) * 8 * (size_t)(nT > 0 ? nT : 1), 256);
+    if (total_bytes) *total_bytes = off;
+    return w;
+}
+
+inline int fill_anchors(Anchors& an, const float* host, int A, int fields, double stride) {
+    if (A < 1 || A > MAXA) return CY_ERR_ARG;
+    for (int a = 0; a < MAXA; ++a) { an.w[a] = an.h[a] = 1.f; an.im[a] = 0.f; an.re[a] = 1.f; }
+    for (int a = 0; a < A; ++a) {
+        an.w[a] = (float)((double)host[a * fields + 0] / stride);
+        an.h[a] = (float)((double)host[a * fields + 1] / stride);
+        if (fields == 4) { an.im[a] = host[a * 4 + 2]; an.re[a] = host[a * 4 + 3]; }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cy_yolo_decode(const float* logits, int B, int G, int A, int C, const float* anchors_host,
+                              float img_size, float* out, int rows_total, int row_offset, cy_stream_t s) {
+    if (!logits || !out || !anchors_host || C < 1 || C > 23 || 7 + C > 32) return CY_ERR_ARG;
+    Anchors an;
+    const double stride = (double)img_size / (double)G;
+    if (fill_anchors(an, anchors_host, A, 2, stride)) return CY_ERR_ARG;
+    const long total = (long)B * G * G * A;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(256), 0, cy_s(s), logits, B, G, A, C, an, (float)stride, out,
+                       rows_total, row_offset);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t cy_yolo_loss_workspace(int B, int G, int A, int C, int nT) {
+    (void)C;
+    const long cells = (long)B * A * G * G;
+    size_t z, total;
+    (void)carve(nullptr, cells, nT, &z, &total);
+    return (int64_t)total;
+}
+
+extern "C" int cy_yolo_loss(const float* logits, int B, int G, int A, int C, const float* targets, int nT,
+                            const float* anchors_host, float img_size, float ignore_thresh, int use_giou,
+                            void* workspace, float* metrics, float* dlogits, cy_stream_t s) {
+    if (!logits || !workspace || !metrics || !dlogits || !anchors_host || nT < 0 || (nT > 0 && !targets))
+        return CY_ERR_ARG;
+    if (C < 1 || C > 23 || 7 + C > 32) return CY_ERR_ARG;
+    Anchors an;
+    const double stride = (double)img_size / (double)G;
+    if (fill_anchors(an, anchors_host, A, 4, stride)) return CY_ERR_ARG;
+    const long cells = (long)B * A * G * G;
+    size_t zero_bytes;
+    Work w = carve(workspace, cells, nT, &zero_bytes);
+    if (hipMemsetAsync(workspace, 0, zero_bytes, cy_s(s)) != hipSuccess) return -(1000 + 1);
+    const LossScales ls = {100.f, 1.f, 3.54f, 3.54f, 64.3f, 37.4f};  // reference yolo_layer.py:40-45
+    Scales sc;
+    if (use_giou) {
+        sc.gx = sc.gy = sc.gw = sc.gh = 0.f;
+        sc.geul = ls.leular; sc.gobj = ls.lobj; sc.gnoobj = ls.lobj; sc.gcls = ls.lcls;
+    } else {
+        sc.gx = sc.gy = sc.gw = sc.gh = 1.f;
+        sc.geul = 1.f; sc.gobj = ls.obj; sc.gnoobj = ls.noobj; sc.gcls = 1.f;
+    }
+    const int tb = (nT + 63) / 64;
+    if (nT > 0) {
+        hipLaunchKernelGGL(assign_kernel, dim3(tb), dim3(64), 0, cy_s(s), targets, nT, B, G, A, an, ignore_thresh, w);
+        hipLaunchKernelGGL(pairs_kernel, dim3(tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, use_giou, w);
+    }
+    const int grid = (int)((cells + 255) / 256 > 2048 ? 2048 : (cells + 255) / 256);
+    hipLaunchKernelGGL(dense_kernel, dim3(grid), dim3(256), 0, cy_s(s), logits, targets, B, G, A, C, an, sc, w, dlogits);
+    if (nT > 0 && use_giou)
+        hipLaunchKernelGGL(giou_grad_kernel, dim3(tb), dim3(64), 0, cy_s(s), logits, nT, G, A, C, an,
+                           ls.lgiou / (float)nT, w, dlogits);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, cy_s(s), w, cells, nT, C, use_giou, ls, metrics);
+    CY_LAUNCH_CHECK();
+    return 0;
+}

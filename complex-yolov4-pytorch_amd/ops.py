@@ -1,0 +1,315 @@
+"""Python-side operator layer: one function per C-ABI entry point (include/cyolo_hip.h), taking torch
+device tensors / NHWC views and launching on torch's current HIP stream.  PyTorch is used for device
+memory and streams only; every computation below happens in libcyolo_hip.so.  No CPU fallback."""
+import ctypes
+
+import torch
+
+from ._lib import CyoloError, lib
+
+CY_F16, CY_F32 = 0, 2
+ACT = {'linear': 0, 'leaky': 1, 'mish': 2}
+CONV_STATS, CONV_BIAS_F32OUT, CONV_ACCUM, CONV_TRANSPOSED = 1, 2, 4, 8
+_TORCH_DT = {CY_F16: torch.float16, CY_F32: torch.float32}
+_ELSIZE = {CY_F16: 2, CY_F32: 4}
+
+
+def dtype_code(name):
+    """'f16' / 'f32' (or the codes themselves) -> CY_F16 / CY_F32."""
+    if name in (CY_F16, 'f16', 'fp16', 'half', torch.float16):
+        return CY_F16
+    if name in (CY_F32, 'f32', 'fp32', 'float', torch.float32):
+        return CY_F32
+    raise ValueError('unsupported dtype %r' % (name,))
+
+
+def torch_dtype(code):
+    return _TORCH_DT[code]
+
+
+def chunk(code):
+    return 8 if code == CY_F16 else 4
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if isinstance(t, View):
+        return ctypes.c_void_p(t.ptr)
+    assert t.is_cuda and t.is_contiguous(), 'device pointer arguments must be contiguous CUDA tensors'
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise CyoloError('no HIP device: the hot path has no CPU fallback')
+
+
+class View:
+    """NHWC view (N,H,W,C) with channel stride ld over a flat device buffer, starting `off` elements in."""
+    __slots__ = ('buf', 'off', 'N', 'H', 'W', 'C', 'ld', 'dt')
+
+    def __init__(self, buf, off, N, H, W, C, ld, dt):
+        self.buf, self.off, self.N, self.H, self.W, self.C, self.ld, self.dt = buf, off, N, H, W, C, ld, dt
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.off * _ELSIZE[self.dt]
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+    def channels(self, c0, c):
+        return View(self.buf, self.off + c0, self.N, self.H, self.W, c, self.ld, self.dt)
+
+    def to_nchw(self):
+        """Materialise as an NCHW float32 torch tensor (test/debug helper)."""
+        flat = self.buf.view(-1)[self.off:self.off + (self.M - 1) * self.ld + self.C]
+        t = torch.as_strided(flat, (self.N, self.H, self.W, self.C), (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1))
+        return t.permute(0, 3, 1, 2).float().contiguous()
+
+    @staticmethod
+    def alloc(N, H, W, C, dt, ld=None, device='cuda', zero=False):
+        ld = ld or C
+        mk = torch.zeros if zero else torch.empty
+        return View(mk(N * H * W * ld, dtype=_TORCH_DT[dt], device=device), 0, N, H, W, C, ld, dt)
+
+    @staticmethod
+    def from_nchw(x, dt, cpad=None, ld=None):
+        """NCHW float tensor -> NHWC view of dtype dt (host-side permute; test helper)."""
+        N, C, H, W = x.shape
+        cp = cpad or C
+        ld = ld or cp
+        buf = torch.zeros(N, H, W, ld, dtype=_TORCH_DT[dt], device=x.device)
+        buf[..., :C] = x.permute(0, 2, 3, 1).to(_TORCH_DT[dt])
+        return View(buf.view(-1), 0, N, H, W, cp, ld, dt)
+
+
+# ---- conv stack ---------------------------------------------------------------------------------
+
+def pack_weights(w, co_pad, ci_pad, dt, want_dgrad=True):
+    """w: fp32 [Co,Ci,k,k] device tensor -> (wf [CoPad, k*k*CiPad], wd [CiPad, k*k*CoPad] or None)."""
+    _require_gpu()
+    Co, Ci, ks, _ = w.shape
+    wf = torch.empty(co_pad, ks * ks * ci_pad, dtype=_TORCH_DT[dt], device=w.device)
+    wd = torch.empty(ci_pad, ks * ks * co_pad, dtype=_TORCH_DT[dt], device=w.device) if want_dgrad else None
+    lib().call('cy_pack_weights', _p(w.detach().contiguous()), Co, Ci, ks, co_pad, ci_pad, dt, _p(wf), _p(wd), _stream())
+    return wf, wd
+
+
+def pack_weights_into(w, co_pad, ci_pad, dt, wf, wd):
+    Co, Ci, ks, _ = w.shape
+    lib().call('cy_pack_weights', _p(w), Co, Ci, ks, co_pad, ci_pad, dt, _p(wf), _p(wd), _stream())
+
+
+def nchw_to_nhwc(x, cpad, dt, out=None):
+    _require_gpu()
+    N, C, H, W = x.shape
+    out = out or View.alloc(N, H, W, cpad, dt, device=x.device)
+    lib().call('cy_nchw_to_nhwc', _p(x.contiguous()), N, C, H, W, cpad, dt, _p(out), _stream())
+    return out
+
+
+def conv_stats_rows(M, OC):
+    return lib().raw('cy_conv_stats_rows')(M, OC)
+
+
+def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None):
+    """Forward conv (or dgrad with CONV_TRANSPOSED).  g/out: Views; w: packed weight tensor."""
+    _require_gpu()
+    lib().call('cy_conv_igemm', _p(g), g.N, g.H, g.W, g.C, g.ld, _p(w), wrows, _p(out), out.H, out.W, out.C, out.ld, ks,
+               stride, pad, g.dt, flags, _p(bias), _p(stats), None, _stream())
+
+
+def wgrad_split(M, Co, Ci, ks):
+    return lib().raw('cy_conv_wgrad_split')(M, Co, Ci, ks)
+
+
+def conv_wgrad(dy, x, ks, stride, pad, part, split, use_tr=1):
+    _require_gpu()
+    lib().call('cy_conv_wgrad', _p(dy), dy.N, dy.H, dy.W, dy.C, dy.ld, _p(x), x.H, x.W, x.C, x.ld, ks, stride, pad,
+               dy.dt, _p(part), split, use_tr, _stream())
+
+
+def wgrad_reduce(part, split, co_rows, ci_pad, ks, Co, Ci, scale, accumulate, grad):
+    lib().call('cy_wgrad_reduce', _p(part), split, co_rows, ci_pad, ks, Co, Ci, float(scale), int(accumulate), _p(grad),
+               _stream())
+
+
+def bn_finalize(stats, rows, C, count, gamma, beta, rmean, rvar, nbt, momentum, eps, mean, invstd, scale, shift):
+    lib().call('cy_bn_finalize', _p(stats), rows, C, count, _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt),
+               float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), _stream())
+
+
+def bn_eval_affine(gamma, beta, rmean, rvar, eps, scale, shift):
+    lib().call('cy_bn_eval_affine', _p(gamma), _p(beta), _p(rmean), _p(rvar), gamma.numel(), float(eps), _p(scale),
+               _p(shift), _stream())
+
+
+def bn_act_fwd(x, y, res, scale, shift, act):
+    lib().call('cy_bn_act_fwd', _p(x), x.ld, _p(y), y.ld, _p(res), res.ld if res is not None else 0, x.M, x.C, _p(scale),
+               _p(shift), act, x.dt, _stream())
+
+
+def bn_bwd_rows(M, C, dt):
+    return lib().raw('cy_bn_bwd_rows')(M, C, dt)
+
+
+def bn_act_bwd_reduce(x, dy, mean, invstd, scale, shift, act, part):
+    lib().call('cy_bn_act_bwd_reduce', _p(x), x.ld, _p(dy), dy.ld, x.M, x.C, _p(mean), _p(invstd), _p(scale), _p(shift),
+               act, x.dt, _p(part), _stream())
+
+
+def bn_bwd_finalize(part, rows, C, dgs, dbs, ggamma, gbeta, gscale):
+    lib().call('cy_bn_bwd_finalize', _p(part), rows, C, _p(dgs), _p(dbs), _p(ggamma), _p(gbeta), float(gscale), _stream())
+
+
+def bn_act_bwd_apply(x, dy, dx, res_grad, res_accum, mean, invstd, scale, shift, dgs, dbs, act):
+    lib().call('cy_bn_act_bwd_apply', _p(x), x.ld, _p(dy), dy.ld, _p(dx), dx.ld, _p(res_grad),
+               res_grad.ld if res_grad is not None else 0, int(res_accum), x.M, x.C, _p(mean), _p(invstd), _p(scale),
+               _p(shift), _p(dgs), _p(dbs), act, x.dt, _stream())
+
+
+def maxpool_fwd(x, y, k, stride, pad, argmax):
+    lib().call('cy_maxpool_fwd', _p(x), x.N, x.H, x.W, x.C, x.ld, _p(y), y.H, y.W, y.ld, k, stride, pad, _p(argmax), x.dt,
+               _stream())
+
+
+def maxpool_bwd(dy, argmax, dx, k, stride, pad, accumulate, scratch):
+    lib().call('cy_maxpool_bwd', _p(dy), dy.N, dy.H, dy.W, dy.C, dy.ld, _p(argmax), _p(dx), dx.H, dx.W, dx.ld, k, stride,
+               pad, int(accumulate), _p(scratch), dy.dt, _stream())
+
+
+def upsample_fwd(x, y, stride):
+    lib().call('cy_upsample_fwd', _p(x), x.N, x.H, x.W, x.C, x.ld, _p(y), y.ld, stride, x.dt, _stream())
+
+
+def upsample_bwd(dy, dx, stride, accumulate):
+    lib().call('cy_upsample_bwd', _p(dy), dx.N, dx.H, dx.W, dx.C, dy.ld, _p(dx), dx.ld, stride, int(accumulate), dx.dt,
+               _stream())
+
+
+def slice_copy(x, y, accumulate=False):
+    lib().call('cy_slice_copy', _p(x), x.ld, _p(y), y.ld, x.M, x.C, int(accumulate), x.dt, _stream())
+
+
+def slice_add(a, b, y):
+    lib().call('cy_slice_add', _p(a), a.ld, _p(b), b.ld, _p(y), y.ld, a.M, a.C, a.dt, _stream())
+
+
+def f32_to_view(x, M, C, scale, y, cpad):
+    lib().call('cy_f32_to_view', _p(x), M, C, float(scale), _p(y), y.ld, cpad, y.dt, _stream())
+
+
+def bias_grad(dlogits, M, C, scale, gbias):
+    lib().call('cy_bias_grad', _p(dlogits), M, C, float(scale), _p(gbias), _stream())
+
+
+# ---- YOLO head ------------------------------------------------------------------------------------
+
+def _farr(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def yolo_decode(logits, B, G, A, C, anchors_wh, img_size, out, rows_total, row_offset):
+    flat = [v for a in anchors_wh for v in a[:2]]
+    lib().call('cy_yolo_decode', _p(logits), B, G, A, C, _farr(flat), float(img_size), _p(out), rows_total, row_offset,
+               _stream())
+
+
+def yolo_loss_workspace(B, G, A, C, nT):
+    return lib().raw('cy_yolo_loss_workspace')(B, G, A, C, nT)
+
+
+def yolo_loss(logits, B, G, A, C, targets, anchors, img_size, ignore_thresh, use_giou, workspace, metrics, dlogits):
+    nT = 0 if targets is None else targets.shape[0]
+    flat = [v for a in anchors for v in a[:4]]
+    lib().call('cy_yolo_loss', _p(logits), B, G, A, C, _p(targets) if nT else None, nT, _farr(flat), float(img_size),
+               float(ignore_thresh), int(bool(use_giou)), _p(workspace), _p(metrics), _p(dlogits), _stream())
+
+
+# ---- geometry / NMS ---------------------------------------------------------------------------------
+
+def riou_pairs(pred, target, giou):
+    _require_gpu()
+    n = pred.shape[0]
+    dev = pred.device
+    ious = torch.empty(n, device=dev)
+    terms = torch.empty(n, device=dev)
+    g = torch.empty(n, 6, device=dev)
+    lib().call('cy_riou_pairs', _p(pred.float().contiguous()), _p(target.float().contiguous()), n, int(bool(giou)),
+               _p(ious), _p(terms), _p(g), _stream())
+    return ious, terms, g
+
+
+def riou_anchors(anchors_wlir, targets_wlir):
+    _require_gpu()
+    nA, nT = anchors_wlir.shape[0], targets_wlir.shape[0]
+    out = torch.empty(nA, nT, device=targets_wlir.device)
+    lib().call('cy_riou_anchors', _p(anchors_wlir.float().contiguous()), nA, _p(targets_wlir.float().contiguous()), nT,
+               _p(out), _stream())
+    return out
+
+
+def riou_matrix(a, b, eps=1e-16):
+    _require_gpu()
+    out = torch.empty(a.shape[0], b.shape[0], device=a.device)
+    lib().call('cy_riou_matrix', _p(a.float().contiguous()), a.shape[0], _p(b.float().contiguous()), b.shape[0],
+               float(eps), _p(out), _stream())
+    return out
+
+
+def rnms_greedy(boxes, confs, nms_thresh):
+    _require_gpu()
+    K = boxes.shape[0]
+    dev = boxes.device
+    ws = torch.empty(max(1, lib().raw('cy_rnms_workspace')(1, max(K, 1))), dtype=torch.uint8, device=dev)
+    keep = torch.empty(max(K, 1), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib().call('cy_rnms_greedy', _p(boxes.float().contiguous()), _p(confs.float().contiguous()), K, float(nms_thresh),
+               _p(ws), _p(keep), _p(count), _stream())
+    return keep[:int(count.item())]
+
+
+def pp2(pred, conf_thresh, nms_thresh):
+    """post_processing_v2 on device.  pred [B,N,7+C] device fp32 -> (det [B,Kmax,9], src [B,Kmax], counts [B]) on host
+    sizes; returns python lists per image (device tensors) and the source-row indices."""
+    _require_gpu()
+    B, N, NCH = pred.shape
+    C = NCH - 7
+    dev = pred.device
+    pred = pred.float().contiguous()
+    ws1 = torch.empty(B * N * 8, dtype=torch.uint8, device=dev)
+    cand = torch.empty(B, N, dtype=torch.int32, device=dev)
+    ccount = torch.zeros(B, dtype=torch.int32, device=dev)
+    lib().call('cy_pp2_select', _p(pred), B, N, C, float(conf_thresh), _p(ws1), _p(cand), _p(ccount), _stream())
+    counts = ccount.cpu()
+    kmax = int(counts.max().item())
+    if kmax == 0:
+        return [None] * B, [None] * B
+    kmax = (kmax + 63) // 64 * 64
+    ws2 = torch.empty(lib().raw('cy_rnms_workspace')(B, kmax), dtype=torch.uint8, device=dev)
+    det = torch.empty(B, kmax, 9, device=dev)
+    src = torch.empty(B, kmax, dtype=torch.int32, device=dev)
+    dcount = torch.zeros(B, dtype=torch.int32, device=dev)
+    lib().call('cy_pp2_merge', _p(pred), B, N, C, _p(cand), _p(ccount), kmax, float(nms_thresh), _p(ws2), _p(det),
+               _p(src), _p(dcount), _stream())
+    dc = dcount.cpu()
+    outs, srcs = [], []
+    for b in range(B):
+        n = int(dc[b])
+        outs.append(det[b, :n] if n else None)
+        srcs.append(src[b, :n] if n else None)
+    return outs, srcs
+
+
+def probe_tr16():
+    _require_gpu()
+    out = torch.zeros(64, 4, dtype=torch.int16, device='cuda')
+    lib().call('cy_probe_tr16', _p(out), _stream())
+    return out

@@ -1,0 +1,199 @@
+/*
+ * cyolo_hip.h -- C ABI of libcyolo_hip.so, the MI355X (gfx950) hot path of Complex-YOLOv4.
+ *
+ * The reference (maudzung/Complex-YOLOv4-Pytorch) has no native operator API: its hot path is a set
+ * of Python call sites.  Every entry point below names the reference interface it
+ * stands behind (file:line under /root/reference/src).  Conventions, all entry points:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer owned by the caller
+ *     (torch-allocated), unless the name ends in _host;
+ *   - stream-ordered on the given hipStream_t, no internal synchronisation, no allocation;
+ *   - returns 0 on success, CY_ERR_ARG (-1) for a rejected argument, -(1000+hipError_t) when a
+ *     launch failed; never throws;
+ *   - activations are NHWC "views": element (n,h,w,c) of a view with channel stride ld lives at
+ *     base[((n*H + h)*W + w)*ld + c]; `dtype` selects the storage type of activations/weights
+ *     (CY_F16 = performance mode, CY_F32 = parity mode, exact f32 MFMA); accumulation is always f32.
+ */
+#ifndef CYOLO_HIP_H
+#define CYOLO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cy_stream_t; /* a hipStream_t */
+
+enum { CY_F16 = 0, CY_F32 = 2 };
+enum { CY_ACT_LINEAR = 0, CY_ACT_LEAKY = 1, CY_ACT_MISH = 2 };
+enum { CY_ERR_ARG = -1 };
+/* cy_conv_igemm flags */
+enum { CY_CONV_STATS = 1, CY_CONV_BIAS_F32OUT = 2, CY_CONV_ACCUM = 4, CY_CONV_TRANSPOSED = 8 };
+
+int cy_version(void);
+/* Number of compute units / wavefront size of the current device (sanity for the loader). */
+int cy_device_info(int* cus, int* wave);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution stack  (reference: nn.Sequential(Conv2d, BatchNorm2d, Mish|LeakyReLU) built at
+ * models/darknet2pytorch.py:247-278 and run at :178; backward = torch autograd of the same)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* fp32 OIHW torch weights [Co][Ci][ks][ks] -> packed `dtype` matrices
+ *   wf [CoPad][ks*ks*CiPad]  (forward / wgrad layout, K index = (kh*ks+kw)*CiPad + ci)
+ *   wd [CiPad][ks*ks*CoPad]  (dgrad layout,          K index = (kh*ks+kw)*CoPad + co), may be NULL.
+ * Padding rows/columns are written as zero. */
+int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad, int CiPad, int dtype, void* wf, void* wd,
+                    cy_stream_t s);
+
+/* NCHW fp32 image batch [N][C][H][W] -> NHWC `dtype` view with CPad channels (extra channels zero).
+ * (reference: the imgs tensor handed to Darknet.forward, darknet2pytorch.py:162) */
+int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dtype, void* out, cy_stream_t s);
+
+/* Implicit-GEMM convolution on MFMA.  One kernel family serves
+ *   forward : out[n,oh,ow,co] = sum_{kh,kw,ci} g[n, oh*stride-pad+kh, ow*stride-pad+kw, ci] * w[co][(kh,kw,ci)]
+ *   dgrad   : (CY_CONV_TRANSPOSED) out = dX, g = dY, w = wd:  gh = (oh+pad-kh)/stride when divisible
+ * g: view (N,GH,GW,GC,ldg);  out: view (N,OH,OW,OC,ldo);  w: [wrows][ks*ks*GC].
+ * flags: CY_CONV_STATS       -> also write per-channel partial (sum, sumsq) of the f32 accumulators to
+ *                               stats_part[prow][2][OC], prow = 2*mtile + half  (BatchNorm batch statistics)
+ *        CY_CONV_BIAS_F32OUT -> out is float regardless of dtype and bias[OC] is added (the YOLO head convs)
+ *        CY_CONV_ACCUM       -> out += result (gradient fan-in of routes / shortcuts)
+ * Returns the number of stats rows written through *stats_rows when non-NULL. */
+int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out, int OH,
+                  int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags, const float* bias,
+                  float* stats_part, int* stats_rows_host, cy_stream_t s);
+/* Upper bound of stats rows cy_conv_igemm writes for M = N*OH*OW output pixels. */
+int cy_conv_stats_rows(int M, int OC);
+
+/* Weight gradient: part[sp][CoRows][ks*ks*Ci] = sum over the pixels of split sp of dy[p][co] * x[p (+) tap][ci].
+ * dy: view (N,OH,OW,Co,lddy) ; x: view (N,XH,XW,Ci,ldx).  `split` partial slabs are written (not accumulated);
+ * cy_wgrad_reduce folds them into the torch-layout gradient. */
+int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int lddy, const void* x, int XH, int XW, int Ci,
+                  int ldx, int ks, int stride, int pad, int dtype, float* part, int split, int use_tr, cy_stream_t s);
+/* Recommended split for the given problem (fills the chip, bounded slab memory). */
+int cy_conv_wgrad_split(int M, int Co, int Ci, int ks);
+/* grad[co][ci][kh][kw] (+)= scale * sum_sp part[sp][co][(kh*ks+kw)*CiPad + ci]   (fp32 OIHW, real Co x Ci) */
+int cy_wgrad_reduce(const float* part, int split, int CoRows, int CiPad, int ks, int Co, int Ci, float scale,
+                    int accumulate, float* grad, cy_stream_t s);
+
+/* BatchNorm2d training statistics from the conv epilogue partials (torch defaults: biased variance for
+ * normalisation, unbiased for running_var; reference darknet2pytorch.py:260).
+ * Writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale and updates running stats
+ * (momentum) and num_batches_tracked (int64, may be NULL). */
+int cy_bn_finalize(const float* stats_part, int rows, int C, int64_t count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                   float* mean, float* invstd, float* scale, float* shift, cy_stream_t s);
+/* Eval-mode affine from running statistics. */
+int cy_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      int C, float eps, float* scale, float* shift, cy_stream_t s);
+/* y = act(x*scale[c] + shift[c]) (+ res)   -- BN apply + Mish/leaky (+ the [shortcut] add,
+ * darknet2pytorch.py:208-219) in one pass.  x: (M pixels, C, ldx); y: ldy; res may be NULL. */
+int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
+                  const float* scale, const float* shift, int act, int dtype, cy_stream_t s);
+/* Backward pass 1: per-channel partial sums of dz and dz*xhat, dz = dy*act'(x*scale+shift).
+ * part[blocks][2][C]; returns rows via cy_bn_bwd_rows. */
+int cy_bn_act_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, int64_t M, int C, const float* mean,
+                         const float* invstd, const float* scale, const float* shift, int act, int dtype,
+                         float* part, cy_stream_t s);
+int cy_bn_bwd_rows(int64_t M, int C, int dtype);
+/* Fold the partials: dgamma_sum[C], dbeta_sum[C] (raw sums, used by the apply pass) and accumulate
+ * gscale*sums into the parameter gradients ggamma/gbeta (+=). */
+int cy_bn_bwd_finalize(const float* part, int rows, int C, float* dgamma_sum, float* dbeta_sum, float* ggamma,
+                       float* gbeta, float gscale, cy_stream_t s);
+/* Backward pass 2: dx = scale*(dz - dbeta/M - xhat*dgamma/M), written to dx (may alias dy).  When
+ * res_grad is non-NULL the shortcut branch gradient dy is added into it (res_accum) or stored. */
+int cy_bn_act_bwd_apply(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, void* res_grad,
+                        int ldrg, int res_accum, int64_t M, int C, const float* mean, const float* invstd,
+                        const float* scale, const float* shift, const float* dgamma_sum, const float* dbeta_sum,
+                        int act, int dtype, cy_stream_t s);
+
+/* Data-movement blocks of Darknet.forward (darknet2pytorch.py:180-219, :64-79, :285). */
+int cy_maxpool_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int OH, int OW, int ldy, int k,
+                   int stride, int pad, uint8_t* argmax, int dtype, cy_stream_t s);
+int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int lddy, const uint8_t* argmax, void* dx, int H,
+                   int W, int lddx, int k, int stride, int pad, int accumulate, float* scratch, int dtype,
+                   cy_stream_t s);
+int cy_upsample_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, int stride, int dtype,
+                    cy_stream_t s);
+int cy_upsample_bwd(const void* dy, int N, int H, int W, int C, int lddy, void* dx, int lddx, int stride,
+                    int accumulate, int dtype, cy_stream_t s);
+/* y (+)= x over a channel slice view (route concat fallback / shortcut without fusion / grad fan-in). */
+int cy_slice_copy(const void* x, int ldx, void* y, int ldy, int64_t M, int C, int accumulate, int dtype,
+                  cy_stream_t s);
+/* y = a + b (shortcut add when it cannot be fused into bn_act). */
+int cy_slice_add(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int64_t M, int C, int dtype,
+                 cy_stream_t s);
+/* fp32 rows [M][C] (ld = C) -> `dtype` view with CPad channels, scaled; used for d(logits) -> head conv backward */
+int cy_f32_to_view(const float* x, int64_t M, int C, float scale, void* y, int ldy, int CPad, int dtype,
+                   cy_stream_t s);
+/* bias gradient of a head conv: gbias[c] += scale * sum_p dlogits[p][c] */
+int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, float* gbias, cy_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * YOLO head  (reference models/yolo_layer.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Decode (yolo_layer.py:144-189): logits NHWC fp32 [B][G][G][A*(7+C)] -> out rows
+ * out[b][row_offset + (a*G+gy)*G+gx][0..6+C] of a [B][rows_total][7+C] fp32 tensor.
+ * anchors: A*(w,h) in input pixels (host array). */
+int cy_yolo_decode(const float* logits, int B, int G, int A, int C, const float* anchors_host, float img_size,
+                   float* out, int rows_total, int row_offset, cy_stream_t s);
+
+/* Workspace size in bytes for cy_yolo_loss. */
+int64_t cy_yolo_loss_workspace(int B, int G, int A, int C, int nT);
+/* Fused build_targets + loss + metrics + d(loss)/d(logits) (yolo_layer.py:69-142, :199-251, and the
+ * autograd of both).  targets: device [nT][8] rows (sample, class, x, y, w, l, im, re).
+ * anchors_host: A*(w, h, im, re) in input pixels.  use_giou selects the loss variant (:213-218).
+ * Outputs: metrics[20] device floats = the 18 entries of YoloLayer.metrics in the reference's key
+ * order + [18] = nObj, [19] = error flag; dlogits fp32 [B][G][G][A*(7+C)] = d(total_loss)/d(logits). */
+int cy_yolo_loss(const float* logits, int B, int G, int A, int C, const float* targets, int nT,
+                 const float* anchors_host, float img_size, float ignore_thresh, int use_giou, void* workspace,
+                 float* metrics, float* dlogits, cy_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotated-box geometry  (reference utils/iou_rotated_boxes_utils.py, utils/cal_intersection_rotated_boxes.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* iou_pred_vs_target_boxes (iou_rotated_boxes_utils.py:98-142): n box pairs (x,y,w,l,im,re).
+ * giou=1: float32 clip with the reference's control flow (incl. its disjoint-pair behaviour, SURVEY
+ * App. A #0) + hull area; giou=0: float64 exact clip.  ious[n], terms[n] (per-pair loss term; the
+ * reference returns their sum), gpred[n][6] = d(term)/d(pred) with the reference's partial gradient. */
+int cy_riou_pairs(const float* pred, const float* target, int n, int giou, float* ious, float* terms, float* gpred,
+                  cy_stream_t s);
+/* iou_rotated_boxes_targets_vs_anchors (:64-95): shapes (w,l,im,re) at a common centre, float64 clip.
+ * ious[nA][nT]. */
+int cy_riou_anchors(const float* anchors_wlir, int nA, const float* targets_wlir, int nT, float* ious,
+                    cy_stream_t s);
+/* Pairwise rotated IoU matrix, float64 clip, float32 tail (evaluation_utils.py:193-218, :24-40). */
+int cy_riou_matrix(const float* a, int na, const float* b, int nb, float eps, float* iou, cy_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotated NMS  (reference utils/evaluation_utils.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* nms_cpu (:250-276): class-agnostic greedy NMS; keep[0..*count) = original indices, highest
+ * confidence first.  workspace bytes: cy_rnms_workspace(1, K) (also sizes cy_pp2_merge with B images, Kmax). */
+int64_t cy_rnms_workspace(int B, int K);
+int cy_rnms_greedy(const float* boxes, const float* confs, int K, float nms_thresh, void* workspace, int32_t* keep,
+                   int32_t* count, cy_stream_t s);
+/* post_processing_v2 (:321-357), phase 1: per image, select rows with objectness >= conf_thresh,
+ * rank them by obj*max(cls) (ties: lower row first).  cand_idx[B][N] (ranked original rows),
+ * cand_count[B]. */
+int cy_pp2_select(const float* pred, int B, int N, int C, float conf_thresh, void* workspace /* B*N*8 bytes */,
+                  int32_t* cand_idx, int32_t* cand_count, cy_stream_t s);
+/* phase 2: same-class merge-NMS over the ranked candidates (at most Kmax per image).
+ * det[B][Kmax][9] rows (x,y,w,l,im,re,obj,cls_conf,cls_id), det_src[B][Kmax] original row of each
+ * detection, det_count[B]. */
+int cy_pp2_merge(const float* pred, int B, int N, int C, const int32_t* cand_idx, const int32_t* cand_count,
+                 int Kmax, float nms_thresh, void* workspace, float* det, int32_t* det_src, int32_t* det_count,
+                 cy_stream_t s);
+
+/* Probe used by the test-suite to pin the gfx950 LDS transpose-read lane mapping the wgrad kernel
+ * relies on: out[64][4] = what each lane receives from ds_read_b64_tr_b16 over a 16x16 u16 tile
+ * holding its own linear index. */
+int cy_probe_tr16(uint16_t* out, cy_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
