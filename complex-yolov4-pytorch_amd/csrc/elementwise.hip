@@ -276,9 +276,11 @@ __global__ void maxpool_bwd_scatter_kernel(const T* __restrict__ dy, int N, int 
 }
 
 template <typename T>
-__global__ void f32_to_view_kernel(const float* __restrict__ x, long M, int C, float scale, T* __restrict__ y, int ldy,
-                                   int CPad, int accumulate) {
+__global__ void f32_to_view_kernel(const float* __restrict__ x, long M, int C, float scale,
+                                   const float* __restrict__ scale_dev, T* __restrict__ y, int ldy, int CPad,
+                                   int accumulate) {
     const long total = M * CPad;
+    if (scale_dev) scale *= *scale_dev;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long p = i / CPad;
         const int c = (int)(i - p * CPad);
@@ -355,7 +357,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Co, int Ci,
     }
 }
 
-__global__ void bias_grad_kernel(const float* __restrict__ d, long M, int C, float scale, float* gbias) {
+__global__ void bias_grad_kernel(const float* __restrict__ d, long M, int C, float scale,
+                                 const float* __restrict__ scale_dev, float* gbias) {
+    if (scale_dev) scale *= *scale_dev;
     // block b handles channel b: strided sum over pixels
     const int c = blockIdx.x;
     double s = 0.0;
@@ -554,7 +558,7 @@ extern "C" int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int 
     hipLaunchKernelGGL((maxpool_bwd_scatter_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), (const T*)dy, N, OH, OW, C, lddy, \
                        argmax, scratch, H, W, k, stride, pad);                                                         \
     hipLaunchKernelGGL((f32_to_view_kernel<T>), dim3(g2), dim3(256), 0, cy_s(s), (const float*)scratch,                \
-                       (long)N * H * W, C, 1.f, (T*)dx, lddx, C, accumulate);
+                       (long)N * H * W, C, 1.f, (const float*)nullptr, (T*)dx, lddx, C, accumulate);
     CY_DT_SWITCH(dtype, CY_MB(f16), CY_MB(float))
 #undef CY_MB
     CY_LAUNCH_CHECK();
@@ -587,12 +591,12 @@ extern "C" int cy_upsample_bwd(const void* dy, int N, int H, int W, int C, int l
     return 0;
 }
 
-extern "C" int cy_f32_to_view(const float* x, int64_t M, int C, float scale, void* y, int ldy, int CPad, int dtype,
-                              cy_stream_t s) {
+extern "C" int cy_f32_to_view(const float* x, int64_t M, int C, float scale, const float* scale_dev, void* y,
+                              int ldy, int CPad, int dtype, cy_stream_t s) {
     if (!x || !y || CPad < C || ldy < CPad) return CY_ERR_ARG;
     const int g = grid_for(M * CPad);
 #define CY_FV(T) \
-    hipLaunchKernelGGL((f32_to_view_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), x, (long)M, C, scale, (T*)y, ldy, CPad, 0);
+    hipLaunchKernelGGL((f32_to_view_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), x, (long)M, C, scale, scale_dev, (T*)y, ldy, CPad, 0);
     CY_DT_SWITCH(dtype, CY_FV(f16), CY_FV(float))
 #undef CY_FV
     CY_LAUNCH_CHECK();
@@ -623,9 +627,10 @@ extern "C" int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad
     return 0;
 }
 
-extern "C" int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, float* gbias, cy_stream_t s) {
+extern "C" int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, const float* scale_dev,
+                            float* gbias, cy_stream_t s) {
     if (!dlogits || !gbias || C < 1) return CY_ERR_ARG;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, cy_s(s), dlogits, (long)M, C, scale, gbias);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, cy_s(s), dlogits, (long)M, C, scale, scale_dev, gbias);
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,203 @@
+"""Darknet -- drop-in for reference src/models/darknet2pytorch.py:147-233: ``Darknet(cfgfile, use_giou_loss)``,
+``forward(x, targets=None)`` -> ``yolo_outputs`` or ``(loss, yolo_outputs)``, attributes ``blocks``, ``models``
+(an ``nn.ModuleList`` with the reference's module / parameter names, so state dicts are interchangeable),
+``yolo_layers``, ``width``, ``height``, ``num_classes``, ``print_network()``.
+
+The torch modules in ``self.models`` only OWN the parameters and buffers.  The computation is a plan of HIP
+kernels (models/graph.py, models/engine.py): NHWC half-precision (or exact-f32 parity mode) activations,
+MFMA implicit-GEMM convolutions with BatchNorm statistics in the epilogue, fused BN+Mish(+shortcut) passes,
+routes as channel slices, fused YOLO head loss.  There is no CPU fallback: a CPU input raises.
+
+Differences from the reference that a caller can observe (all deliberate):
+  * in training the returned ``yolo_outputs`` stays on the device (the reference copies it to the host every
+    step and train.py discards it, #15); with ``targets=None`` it is a CPU tensor as in the reference;
+  * parameter gradients are accumulated by the backward kernels straight into one flat fp32 buffer whose
+    slices are the parameters' ``.grad`` (this is what the data-parallel wrapper all-reduces);
+  * ``dtype='f16'`` (default) computes in fp16 with fp32 accumulation; ``dtype='f32'`` is the parity mode.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .darknet_utils import parse_cfg, print_cfg
+from .engine import Engine
+from .graph import Plan, lower_blocks
+from .yolo_layer import YoloLayer
+
+
+class Mish(nn.Module):
+    """Parameter-free placeholder keeping the reference's module tree (``mish{n}``); the activation itself
+    runs fused in cy_bn_act_fwd (reference darknet2pytorch.py:22-28)."""
+
+    def forward(self, x):  # pragma: no cover - never on the hot path
+        raise ops.CyoloError('activation modules are placeholders; run the model through Darknet.forward')
+
+
+class EmptyModule(nn.Module):
+    """Placeholder for route / shortcut / pool / upsample entries of the module list."""
+
+    def __init__(self, kind=''):
+        super().__init__()
+        self.kind = kind
+
+    def forward(self, x):  # pragma: no cover
+        raise ops.CyoloError('structural modules are placeholders; run the model through Darknet.forward')
+
+
+class _StepFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward runs the plan, backward runs the backward plan and
+    deposits parameter gradients into the model's flat gradient buffer (so it returns None for them)."""
+
+    @staticmethod
+    def forward(ctx, model, x, targets, *params):
+        eng = model._engine_for(x)
+        outputs = eng.forward(x, targets, model._param_table(), model.use_giou_loss, x.shape[2])
+        model._publish_metrics(eng)
+        heads = [m[0] for m in eng.metrics]
+        total = heads[0].clone()
+        for h in heads[1:]:
+            total += h
+        ctx.model, ctx.eng = model, eng
+        ctx.mark_non_differentiable(outputs)
+        return (total.reshape(1) if model.use_giou_loss else total), outputs
+
+    @staticmethod
+    def backward(ctx, gloss, _gout):
+        model, eng = ctx.model, ctx.eng
+        if not eng.training:
+            raise ops.CyoloError('backward needs model.train(): eval-mode engines keep no activations')
+        grads = model._grad_table()
+        eng.backward(grads, gloss.detach().reshape(-1).float().contiguous(), model.loss_scale)
+        for hook in model._post_backward_hooks:
+            hook(model)
+        return (None, None, None) + (None,) * len(model._plist)
+
+
+class Darknet(nn.Module):
+    def __init__(self, cfgfile, use_giou_loss, dtype='f16', loss_scale=None):
+        super(Darknet, self).__init__()
+        self.use_giou_loss = use_giou_loss
+        self.blocks = parse_cfg(cfgfile)
+        self.width = int(self.blocks[0]['width'])
+        self.height = int(self.blocks[0]['height'])
+        self.dtype_code = ops.dtype_code(dtype)
+        # fp16 activations gradients are scaled to stay clear of the fp16 subnormal range; parity mode needs none
+        self.loss_scale = float(loss_scale if loss_scale is not None else (1024.0 if self.dtype_code == ops.CY_F16 else 1.0))
+        self.models = self.create_network(self.blocks)
+        self.yolo_layers = [layer for layer in self.models if layer.__class__.__name__ == 'YoloLayer']
+        self.loss = self.models[len(self.models) - 1]
+        self.header = torch.IntTensor([0, 0, 0, 0])
+        self.seen = 0
+        self.cpu_outputs = True          # targets=None returns a CPU tensor like the reference (:228)
+        self._plans, self._engines = {}, {}
+        self._plist = None
+        self._grad_flat = None
+        self._post_backward_hooks = []
+
+    # ---- construction (reference create_network :235-401) -----------------------------------------
+    def create_network(self, blocks):
+        models = nn.ModuleList()
+        for m in lower_blocks(blocks):
+            t = m['type']
+            if t == 'convolutional':
+                n = m['n']
+                seq = nn.Sequential()
+                seq.add_module('conv%d' % n, nn.Conv2d(m['cin'], m['cout'], m['k'], m['stride'], m['pad'], bias=not m['bn']))
+                if m['bn']:
+                    seq.add_module('bn%d' % n, nn.BatchNorm2d(m['cout']))
+                if m['act'] == 'leaky':
+                    seq.add_module('leaky%d' % n, nn.LeakyReLU(0.1, inplace=True))
+                elif m['act'] == 'mish':
+                    seq.add_module('mish%d' % n, Mish())
+                elif m['act'] != 'linear':
+                    raise ValueError('unsupported activation %r' % m['act'])
+                models.append(seq)
+            elif t == 'yolo':
+                self.num_classes = m['classes']
+                models.append(YoloLayer(num_classes=m['classes'], anchors=m['anchors'], stride=0,
+                                        scale_x_y=m['scale_x_y'], ignore_thresh=m['ignore_thresh']))
+            else:
+                models.append(EmptyModule(t))
+        return models
+
+    def print_network(self):
+        print_cfg(self.blocks)
+
+    def load_weights(self, weightfile):
+        raise NotImplementedError('Darknet .weights files are outside the hot path (SURVEY.md section 2 row 2); '
+                                  'use load_state_dict with a reference checkpoint')
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def _param_table(self):
+        t = {k: v.data for k, v in self.named_parameters()}
+        t.update({k: v for k, v in self.named_buffers()})
+        return t
+
+    def _engine_for(self, x):
+        N, _, H, W = x.shape
+        pk = (H, W)
+        if pk not in self._plans:
+            self._plans[pk] = Plan(self.blocks, H, W, ops.chunk(self.dtype_code))
+        ek = (N, H, W, self.training, str(x.device))
+        if ek not in self._engines:
+            self._engines[ek] = Engine(self._plans[pk], N, self.dtype_code, x.device, self.training)
+        return self._engines[ek]
+
+    def release_engines(self):
+        """Drop cached device storages (e.g. after multiscale training changed resolution)."""
+        self._engines.clear()
+
+    def _publish_metrics(self, eng):
+        for layer, met in zip(self.yolo_layers, eng.metrics):
+            layer._metrics_dev = met
+
+    def _grad_table(self):
+        """{name: fp32 view into the flat gradient buffer}; attaches the views as ``.grad``.  A parameter whose
+        ``.grad`` is None (zero_grad(set_to_none=True)) gets its slice zeroed; existing values are accumulated
+        into, which is what gradient accumulation over sub-divisions needs (reference train.py:212-221)."""
+        named = list(self.named_parameters())
+        if self._plist is None or len(self._plist) != len(named):
+            self._plist = named
+        if self._grad_flat is None or self._grad_flat.device != named[0][1].device:
+            total = sum(p.numel() for _, p in named)
+            self._grad_flat = torch.zeros(total, dtype=torch.float32, device=named[0][1].device)
+            self._grad_views, off = {}, 0
+            for name, p in named:
+                self._grad_views[name] = self._grad_flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            for _, p in named:
+                p.grad = None
+        if all(p.grad is None for _, p in named):
+            self._grad_flat.zero_()
+            for name, p in named:
+                p.grad = self._grad_views[name]
+        else:
+            for name, p in named:
+                v = self._grad_views[name]
+                if p.grad is None:
+                    v.zero_()
+                    p.grad = v
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                    p.grad = v
+        return self._grad_views
+
+    @property
+    def flat_grad(self):
+        return self._grad_flat
+
+    # ---- forward (reference :162-230) -----------------------------------------------------------
+    def forward(self, x, targets=None):
+        ops.check_device_tensor(x, 'Darknet')
+        x = x.float().contiguous()
+        if targets is None:
+            eng = self._engine_for(x)
+            out = eng.forward(x, None, self._param_table(), self.use_giou_loss, x.shape[2])
+            return out.cpu() if self.cpu_outputs else out.clone()
+        targets = targets.to(x.device).float().contiguous()
+        if self._plist is None:
+            self._plist = list(self.named_parameters())
+        loss, outputs = _StepFn.apply(self, x, targets, *[p for _, p in self._plist])
+        return loss, outputs

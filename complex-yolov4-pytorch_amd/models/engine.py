@@ -1,0 +1,265 @@
+"""Executes a ``graph.Plan`` on the HIP operator layer (``ops``): owns the device storages for one
+(batch, height, width, dtype, mode) and issues the kernels of a forward / backward pass in plan order on
+torch's current HIP stream.  Reference call stack replaced: Darknet.forward (darknet2pytorch.py:162-230)
+with its per-block ATen calls, and the autograd graph ``total_loss.backward()`` walks (train.py:212).
+
+Memory (288 GB HBM3E): every activation, its raw (pre-BN) twin and its gradient are resident for the
+whole step -- nothing is recomputed, nothing is freed between steps.
+"""
+import torch
+
+from .. import ops
+from ..ops import CONV_ACCUM, CONV_BIAS_F32OUT, CONV_STATS, CONV_TRANSPOSED, CY_F32, View
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1          # torch.nn.BatchNorm2d defaults, as the reference uses them
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+class Engine:
+    def __init__(self, plan, N, dt, device, training):
+        self.plan, self.N, self.dt, self.device, self.training = plan, N, dt, device, training
+        self.tdt = ops.torch_dtype(dt)
+        self.act, self.gact = {}, {}
+        f32 = dict(dtype=torch.float32, device=device)
+        max_raw = 0
+        for st in plan.storages:
+            n = N * st.H * st.W * st.C
+            if st.kind == 'logits':
+                self.act[st.sid] = torch.empty(n, **f32)
+            elif st.kind == 'raw':
+                if training:
+                    self.act[st.sid] = torch.empty(n, dtype=self.tdt, device=device)
+                else:
+                    max_raw = max(max_raw, n)
+            else:
+                self.act[st.sid] = torch.empty(n, dtype=self.tdt, device=device)
+                if training and st.kind == 'act':
+                    self.gact[st.sid] = torch.empty(n, dtype=self.tdt, device=device)
+        self.raw_scratch = torch.empty(max(max_raw, 1), dtype=self.tdt, device=device)
+        # per-conv persistent BN vectors and packed weights; shared scratch for the reductions
+        self.bnvec, self.wf, self.wd = {}, {}, {}
+        max_stats = max_bnrows = max_c = 1
+        max_wpart = 1
+        self.wsplit = {}
+        for rec in plan.convs:
+            C, M = rec['cout'], N * rec['H'] * rec['W']
+            cop, cip = _pad32(C), rec['cin_pad']
+            kk = rec['ks'] * rec['ks']
+            self.wf[rec['idx']] = torch.empty(cop, kk * cip, dtype=self.tdt, device=device)
+            self.wd[rec['idx']] = torch.empty(cip, kk * cop, dtype=self.tdt, device=device) if training and not rec['first'] else None
+            if rec['bn']:
+                self.bnvec[rec['idx']] = torch.empty(4, C, **f32)
+                max_stats = max(max_stats, ops.conv_stats_rows(M, C) * 2 * C)
+                max_c = max(max_c, C)
+                if training:
+                    max_bnrows = max(max_bnrows, ops.bn_bwd_rows(M, C, dt) * 2 * C)
+            if training:
+                sp = ops.wgrad_split(M, cop, cip, rec['ks'])
+                self.wsplit[rec['idx']] = sp
+                max_wpart = max(max_wpart, sp * cop * kk * cip)
+        self.stats = torch.empty(max_stats, **f32)
+        self.bnpart = torch.empty(max_bnrows, **f32)
+        self.dgs, self.dbs = torch.empty(max_c, **f32), torch.empty(max_c, **f32)
+        self.wpart = torch.empty(max_wpart if training else 1, **f32)
+        self.dummy = torch.zeros(16, **f32)
+        # pools
+        self.argmax, self.pool_scratch = {}, None
+        max_pool_in = 1
+        for rec in plan.fwd:
+            if rec['op'] == 'pool' and training:
+                o = rec['out']
+                self.argmax[rec['idx']] = torch.empty(N * o.st.H * o.st.W * o.C, dtype=torch.uint8, device=device)
+                x = rec['x']
+                max_pool_in = max(max_pool_in, N * x.st.H * x.st.W * x.C)
+        self.pool_scratch = torch.empty(max_pool_in, **f32)
+        # heads
+        self.outputs = torch.empty(N, plan.rows_total, 7 + plan.heads[0]['C'], **f32) if plan.heads else None
+        self.metrics = [torch.zeros(20, **f32) for _ in plan.heads]
+        self.dlogits, self.head_tmp, self.loss_ws = [], [], []
+        for h in plan.heads:
+            n = N * h['G'] * h['G']
+            self.dlogits.append(torch.empty(n * h['A'] * (7 + h['C']), **f32) if training else None)
+            self.head_tmp.append(View.alloc(N, h['G'], h['G'], 32, dt, device=device) if training else None)
+            self.loss_ws.append(None)
+        self.nT = -1
+
+    # ---- views -----------------------------------------------------------------------------------
+    def view(self, ref, grad=False):
+        st = ref.st
+        if st.kind == 'raw' and not self.training:
+            buf = self.raw_scratch
+        else:
+            buf = (self.gact if grad else self.act)[st.sid]
+        dt = CY_F32 if st.kind == 'logits' else self.dt
+        return View(buf, ref.c0, self.N, st.H, st.W, ref.C, st.C, dt)
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, x, targets, params, use_giou, img_size):
+        plan = self.plan
+        ops.nchw_to_nhwc(x, plan.input.C, self.dt, out=self.view(plan.input))
+        self.params = params
+        for rec in plan.fwd:
+            getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
+        return self.outputs
+
+    def _names(self, rec):
+        i, n = rec['idx'], rec['n']
+        return 'models.%d.conv%d' % (i, n), 'models.%d.bn%d' % (i, n)
+
+    def _f_conv(self, rec, targets, use_giou, img_size):
+        cname, bname = self._names(rec)
+        P = self.params
+        idx = rec['idx']
+        w = P[cname + '.weight']
+        cop = _pad32(rec['cout'])
+        ops.pack_weights_into(w, cop, rec['cin_pad'], self.dt, self.wf[idx], self.wd[idx])
+        xv = self.view(rec['x'])
+        if not rec['bn']:
+            ops.conv_igemm(xv, self.wf[idx], cop, self.view(rec['out']), rec['ks'], rec['stride'], rec['pad'],
+                           flags=CONV_BIAS_F32OUT, bias=P[cname + '.bias'])
+            return
+        raw = self.view(rec['raw'])
+        vec = self.bnvec[idx]
+        mean, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3]
+        C, M = rec['cout'], raw.M
+        if self.training:
+            ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=CONV_STATS,
+                           stats=self.stats)
+            ops.bn_finalize(self.stats, ops.conv_stats_rows(M, C), C, M, P[bname + '.weight'], P[bname + '.bias'],
+                            P[bname + '.running_mean'], P[bname + '.running_var'],
+                            P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, mean, invstd, scale, shift)
+        else:
+            ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'])
+            ops.bn_eval_affine(P[bname + '.weight'], P[bname + '.bias'], P[bname + '.running_mean'],
+                               P[bname + '.running_var'], BN_EPS, scale, shift)
+        res = self.view(rec['res']) if rec['res'] is not None else None
+        ops.bn_act_fwd(raw, self.view(rec['out']), res, scale, shift, ops.ACT[rec['act']])
+
+    def _f_pool(self, rec, *_):
+        ops.maxpool_fwd(self.view(rec['x']), self.view(rec['out']), rec['k'], rec['stride'], rec['pad'],
+                        self.argmax.get(rec['idx']))
+
+    def _f_upsample(self, rec, *_):
+        ops.upsample_fwd(self.view(rec['x']), self.view(rec['out']), rec['stride'])
+
+    def _f_copy(self, rec, *_):
+        ops.slice_copy(self.view(rec['x']), self.view(rec['out']))
+
+    def _f_add(self, rec, *_):
+        ops.slice_add(self.view(rec['a']), self.view(rec['b']), self.view(rec['out']))
+
+    def _f_yolo(self, rec, targets, use_giou, img_size):
+        h = rec['head']
+        logits = self.act[rec['logits'].st.sid]
+        ops.yolo_decode(logits, self.N, rec['G'], rec['A'], rec['C'], rec['anchors'], img_size, self.outputs,
+                        self.plan.rows_total, rec['row_offset'])
+        if targets is None:
+            return
+        nT = targets.shape[0]
+        need = ops.yolo_loss_workspace(self.N, rec['G'], rec['A'], rec['C'], nT)
+        if self.loss_ws[h] is None or self.loss_ws[h].numel() < need:
+            self.loss_ws[h] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        dl = self.dlogits[h]
+        if dl is None:
+            dl = self.dlogits[h] = torch.empty(logits.numel(), dtype=torch.float32, device=self.device)
+        ops.yolo_loss(logits, self.N, rec['G'], rec['A'], rec['C'], targets, rec['anchors'], img_size,
+                      rec['ignore_thresh'], use_giou, self.loss_ws[h], self.metrics[h], dl)
+
+    # ---- backward --------------------------------------------------------------------------------
+    def backward(self, grads, gout_dev, loss_scale):
+        """grads: {param name: fp32 gradient tensor (accumulated into)}; gout_dev: device scalar d(loss)."""
+        assert self.training
+        self.grads, self.gout, self.ls = grads, gout_dev, float(loss_scale)
+        for rec in self.plan.bwd:
+            getattr(self, '_b_' + rec['op'])(rec)
+
+    def _wgrad(self, rec, dy, xv):
+        idx = rec['idx']
+        cname, _ = self._names(rec)
+        cop, cip = _pad32(rec['cout']), rec['cin_pad']
+        sp = self.wsplit[idx]
+        ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], self.wpart, sp)
+        ops.wgrad_reduce(self.wpart, sp, cop, cip, rec['ks'], rec['cout'], rec['cin'], 1.0 / self.ls, True,
+                         self.grads[cname + '.weight'])
+
+    def _dgrad(self, rec, dy, runs):
+        wd = self.wd[rec['idx']]
+        x = rec['x']
+        for ref, acc in runs:
+            r0 = ref.c0 - x.c0
+            ops.conv_igemm(dy, wd[r0:r0 + ref.C], ref.C, self.view(ref, grad=True), rec['ks'], rec['stride'],
+                           rec['pad'], flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0))
+
+    def _b_conv_bwd(self, b):
+        rec = b['fwd']
+        idx = rec['idx']
+        _, bname = self._names(rec)
+        vec = self.bnvec[idx]
+        mean, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3]
+        raw, g = self.view(rec['raw']), self.view(rec['out'], grad=True)
+        C, M = rec['cout'], raw.M
+        act = ops.ACT[rec['act']]
+        ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, self.bnpart)
+        ops.bn_bwd_finalize(self.bnpart, ops.bn_bwd_rows(M, C, self.dt), C, self.dgs, self.dbs,
+                            self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls)
+        res_view, res_acc = None, False
+        runs = b['res_runs']
+        if len(runs) == 1:
+            res_view, res_acc = self.view(runs[0][0], grad=True), runs[0][1]
+        elif len(runs) > 1:
+            res = rec['res']
+            for ref, acc in runs:
+                ops.slice_copy(g.channels(ref.c0 - res.c0, ref.C), self.view(ref, grad=True), accumulate=acc)
+        ops.bn_act_bwd_apply(raw, g, g, res_view, res_acc, mean, invstd, scale, shift, self.dgs, self.dbs, act)
+        self._wgrad(rec, g, self.view(rec['x']))
+        self._dgrad(rec, g, b['dx'])
+
+    def _b_head_conv_bwd(self, b):
+        rec = b['fwd']
+        cname, _ = self._names(rec)
+        h = next(i for i, hd in enumerate(self.plan.heads) if hd['conv'] is rec)
+        hd = self.plan.heads[h]
+        M, nch = self.N * hd['G'] * hd['G'], hd['A'] * (7 + hd['C'])
+        tmp = self.head_tmp[h]
+        ops.f32_to_view(self.dlogits[h], M, nch, self.ls, tmp, 32, scale_dev=self.gout)
+        ops.bias_grad(self.dlogits[h], M, nch, 1.0, self.grads[cname + '.bias'], scale_dev=self.gout)
+        self._wgrad(rec, tmp, self.view(rec['x']))
+        self._dgrad(rec, tmp, b['dx'])
+
+    def _b_pool_bwd(self, b):
+        rec = b['fwd']
+        if len(b['dx']) == 1:
+            ref, acc = b['dx'][0]
+        else:
+            # mixed fan-in state (part of the input already holds a gradient): zero the rest, then accumulate
+            for r, written in b['dx']:
+                if not written:
+                    ops.zero_view(self.view(r, grad=True), self.dummy)
+            ref, acc = rec['x'], True
+        ops.maxpool_bwd(self.view(rec['out'], grad=True), self.argmax[rec['idx']], self.view(ref, grad=True), rec['k'],
+                        rec['stride'], rec['pad'], acc, self.pool_scratch)
+
+    def _b_upsample_bwd(self, b):
+        rec = b['fwd']
+        g, x = self.view(rec['out'], grad=True), rec['x']
+        for ref, acc in b['dx']:
+            ops.upsample_bwd(g.channels(ref.c0 - x.c0, ref.C), self.view(ref, grad=True), rec['stride'], acc)
+
+    def _b_copy_bwd(self, b):
+        rec = b['fwd']
+        g, x = self.view(rec['out'], grad=True), rec['x']
+        for ref, acc in b['dx']:
+            ops.slice_copy(g.channels(ref.c0 - x.c0, ref.C), self.view(ref, grad=True), accumulate=acc)
+
+    def _b_add_bwd(self, b):
+        rec = b['fwd']
+        g = self.view(rec['out'], grad=True)
+        for key, src in (('da', rec['a']), ('db', rec['b'])):
+            for ref, acc in b[key]:
+                ops.slice_copy(g.channels(ref.c0 - src.c0, ref.C), self.view(ref, grad=True), accumulate=acc)
+
+    def _b_zero_grad(self, b):
+        ops.zero_view(self.view(b['ref'], grad=True), self.dummy)

@@ -49,6 +49,12 @@ def _require_gpu():
         raise CyoloError('no HIP device: the hot path has no CPU fallback')
 
 
+def check_device_tensor(t, who):
+    """The hot path has no CPU fallback: a host tensor is an error, not a slow path."""
+    if not t.is_cuda:
+        raise CyoloError('%s runs on the HIP device only (no CPU fallback); got a %s tensor' % (who, t.device))
+
+
 class View:
     """NHWC view (N,H,W,C) with channel stride ld over a flat device buffer, starting `off` elements in."""
     __slots__ = ('buf', 'off', 'N', 'H', 'W', 'C', 'ld', 'dt')
@@ -202,12 +208,17 @@ def slice_add(a, b, y):
     lib().call('cy_slice_add', _p(a), a.ld, _p(b), b.ld, _p(y), y.ld, a.M, a.C, a.dt, _stream())
 
 
-def f32_to_view(x, M, C, scale, y, cpad):
-    lib().call('cy_f32_to_view', _p(x), M, C, float(scale), _p(y), y.ld, cpad, y.dt, _stream())
+def f32_to_view(x, M, C, scale, y, cpad, scale_dev=None):
+    lib().call('cy_f32_to_view', _p(x), M, C, float(scale), _p(scale_dev), _p(y), y.ld, cpad, y.dt, _stream())
 
 
-def bias_grad(dlogits, M, C, scale, gbias):
-    lib().call('cy_bias_grad', _p(dlogits), M, C, float(scale), _p(gbias), _stream())
+def zero_view(y, dummy):
+    """Zero-fill a channel-slice view (f32_to_view with zero source channels)."""
+    lib().call('cy_f32_to_view', _p(dummy), y.M, 0, 0.0, None, _p(y), y.ld, y.C, y.dt, _stream())
+
+
+def bias_grad(dlogits, M, C, scale, gbias, scale_dev=None):
+    lib().call('cy_bias_grad', _p(dlogits), M, C, float(scale), _p(scale_dev), _p(gbias), _stream())
 
 
 # ---- YOLO head ------------------------------------------------------------------------------------

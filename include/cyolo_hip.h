@@ -124,10 +124,13 @@ int cy_slice_copy(const void* x, int ldx, void* y, int ldy, int64_t M, int C, in
 int cy_slice_add(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int64_t M, int C, int dtype,
                  cy_stream_t s);
 /* fp32 rows [M][C] (ld = C) -> `dtype` view with CPad channels, scaled; used for d(logits) -> head conv backward */
-int cy_f32_to_view(const float* x, int64_t M, int C, float scale, void* y, int ldy, int CPad, int dtype,
-                   cy_stream_t s);
-/* bias gradient of a head conv: gbias[c] += scale * sum_p dlogits[p][c] */
-int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, float* gbias, cy_stream_t s);
+int cy_f32_to_view(const float* x, int64_t M, int C, float scale, const float* scale_dev, void* y, int ldy, int CPad,
+                   int dtype, cy_stream_t s);
+/* bias gradient of a head conv: gbias[c] += scale * sum_p dlogits[p][c].
+ * In both calls the effective factor is scale * (*scale_dev) when scale_dev is non-NULL (the upstream
+ * d(loss) scalar stays on the device: no host synchronisation in backward). */
+int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, const float* scale_dev, float* gbias,
+                 cy_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * YOLO head  (reference models/yolo_layer.py)
