@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): BEV images/s of a 608x608 Complex-YOLOv4 TRAIN step.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One step = forward + GIoU loss + backward + Adam update of complex_yolov4.cfg on a fixed synthetic batch of 16 BEV
+images per GPU (BASELINE configs[1]); inputs are resident in HBM before the timed region.  Weak scaling: every rank
+runs its own 16 images, gradients are averaged over RCCL (parallel.RcclDataParallel).  Rank 0 prints ONE JSON line with
+`roofline` (the implicit-GEMM conv kernel, timed with HIP events on its launch stream) and `cpu_baseline` (the oracle --
+a CPU restatement of the reference -- timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import complex_yolov4_pytorch_amd.ops as ops  # noqa: E402
+import complex_yolov4_pytorch_amd.synthetic as syn  # noqa: E402
+from complex_yolov4_pytorch_amd.models.darknet2pytorch import Darknet  # noqa: E402
+from complex_yolov4_pytorch_amd.parallel import RcclDataParallel  # noqa: E402
+from complex_yolov4_pytorch_amd.utils.train_utils import create_optimizer  # noqa: E402
+
+CFG = os.path.join(ROOT, 'complex-yolov4-pytorch_amd', 'config', 'cfg', 'complex_yolov4.cfg')
+MFMA_PEAK_TFLOPS = {'f16': 2500.0, 'f32': 157.3}     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+class _OptCfg:
+    optimizer_type, lr, momentum, weight_decay = 'adam', 1e-3, 0.949, 5e-4     # reference train_config.py:82-94
+
+
+def usable_cores(cap=32):
+    """Cores this process may really use: affinity mask and cgroup CPU quota, capped (oversubscribed OpenMP teams on
+    a 256-thread host made a single oracle step take minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+            if quota != 'max':
+                n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(batch, size, seconds_budget=20.0):
+    """Oracle train step (forward + GIoU loss + backward) on the host cores, bounded sample."""
+    from complex_yolov4_pytorch_amd.models.darknet_utils import parse_cfg
+    from oracle import darknet_ref
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    net = darknet_ref.DarknetRef(parse_cfg(CFG))
+    ps, bs = net.param_shapes()
+    params = {k: v.requires_grad_(True) for k, v in syn.fill_state_dict(ps).items()}
+    bufs = syn.fill_state_dict(bs)
+    x, tg = syn.bev_images(batch, size, seed=0), syn.targets(batch, 6, size, seed=0)
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        _, loss, _ = net.forward(params, x, tg, True, True, bufs)
+        loss.sum().backward()
+
+    t0 = time.time()
+    step()                                  # warm-up (also sizes the sample: a slow host gets one timed step)
+    warm = time.time() - t0
+    t0, n = time.time(), 0
+    while n < 1 or (n < 8 and (time.time() - t0) + warm < seconds_budget):
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=round(batch / dt, 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d timed train steps (fwd+GIoU loss+bwd) of complex_yolov4.cfg, batch %d, %dx%d, fp32, torch-CPU oracle'
+                       % (n, batch, size, size))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU')
+    ap.add_argument('--size', type=int, default=608)
+    ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    torch.manual_seed(0)
+    model = Darknet(CFG, use_giou_loss=True, dtype=a.dtype).to(dev)
+    model.train()
+    net = RcclDataParallel(model) if world > 1 else model
+    opt = create_optimizer(_OptCfg, model)
+    x = syn.bev_images(a.batch, a.size, seed=rank).to(dev)
+    tg = syn.targets(a.batch, 6, a.size, seed=rank).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = net(x, tg)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    sync()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    final_loss = float(loss.detach().reshape(-1)[0])
+
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        ops.PROFILER = ops.LaunchProfiler()
+        for _ in range(2):
+            step()
+        summ = ops.PROFILER.summary()
+        ops.PROFILER = None
+        ig = summ.get('igemm')
+        if ig:
+            ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[a.dtype]
+            roofline = dict(bound='mfma', kernel='igemm_kernel (implicit-GEMM conv: forward + dgrad launches, all tile variants)',
+                            achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                            launches_per_step=ig['launches'] // 2, avg_launch_us=round(1e3 * ig['ms'] / ig['launches'], 2),
+                            hbm_gbs_algorithmic=round(ig['bytes'] / (ig['ms'] * 1e-3) / 1e9, 1),
+                            measured='HIP events around every launch of the kernel on its launch stream, 2 extra steps after the timed region')
+            wg = summ.get('wgrad')
+            if wg:
+                roofline['wgrad_kernel'] = dict(achieved=round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12, 2), unit='TFLOP/s',
+                                                launches_per_step=wg['launches'] // 2,
+                                                avg_launch_us=round(1e3 * wg['ms'] / wg['launches'], 2))
+            roofline['conv_ms_per_step'] = round((ig['ms'] + (wg['ms'] if wg else 0)) / 2, 3)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        cpu = None
+        if not a.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(2, a.size)
+        imgs = world * a.batch * a.steps
+        line = {
+            'metric': 'BEV images/s (608x608) train step', 'value': round(imgs / elapsed, 3), 'unit': 'images/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * elapsed / a.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16' if a.dtype == 'f16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'complex_yolov4.cfg train step (fwd + rotated-GIoU loss + bwd + Adam), batch %d per GPU, %dx%dx3 synthetic BEV, 6 targets/image'
+                                   % (a.batch, a.size, a.size),
+                       'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4)},
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

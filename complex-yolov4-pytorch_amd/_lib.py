@@ -4,6 +4,11 @@ import ctypes
 import os
 import re
 
+# PyTorch must load ITS HIP runtime first: libcyolo_hip.so links libamdhip64.so.7 by soname, and if the system copy
+# under /opt/rocm is mapped before torch's bundled one, torch later finds "No HIP GPUs".  Importing torch here makes
+# the loader resolve our dependency to the runtime torch already mapped (one runtime, shared streams).
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_HERE, '..', 'include', 'cyolo_hip.h')
 LIBPATH = os.path.join(_HERE, 'csrc', 'libcyolo_hip.so')

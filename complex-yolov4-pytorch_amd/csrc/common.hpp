@@ -16,6 +16,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define CY_WAVE 64
 
+// hipGetLastError() is per-thread sticky state shared with every other HIP user in the process (PyTorch included):
+// clear it on entry so that a launch check only ever reports this call's own launches.
+#define CY_ENTER() (void)hipGetLastError()
+
 #define CY_LAUNCH_CHECK()                                   \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \

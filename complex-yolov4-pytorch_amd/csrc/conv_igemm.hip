@@ -323,6 +323,7 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int cy_conv_stats_rows(int M, int OC) {
+    CY_ENTER();
     int bm, bn;
     pick_tile(M, OC, bm, bn);
     return 2 * ((M + bm - 1) / bm);
@@ -331,6 +332,7 @@ extern "C" int cy_conv_stats_rows(int M, int OC) {
 extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows,
                              void* out, int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype,
                              int flags, const float* bias, float* stats_part, int* stats_rows_host, cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!g || !w || !out || (dtype != CY_F16 && dtype != CY_F32)) return CY_ERR_ARG;
     if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2) || GC % ch || ldg % ch) return CY_ERR_ARG;

@@ -275,6 +275,7 @@ __global__ void probe_tr16_kernel(uint16_t* out) {
 }  // namespace
 
 extern "C" int cy_conv_wgrad_split(int M, int Co, int Ci, int ks) {
+    CY_ENTER();
     const int ncols = ks * ks * Ci;
     const long tiles = (long)((Co + tile_of(Co) - 1) / tile_of(Co)) * ((ncols + tile_of(ncols) - 1) / tile_of(ncols));
     long split = (1024 + tiles - 1) / tiles;
@@ -288,6 +289,7 @@ extern "C" int cy_conv_wgrad_split(int M, int Co, int Ci, int ks) {
 extern "C" int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int lddy, const void* x, int XH, int XW,
                              int Ci, int ldx, int ks, int stride, int pad, int dtype, float* part, int split,
                              int use_tr, cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!dy || !x || !part || split < 1 || (dtype != CY_F16 && dtype != CY_F32)) return CY_ERR_ARG;
     if (Co % ch || Ci % ch || lddy % ch || ldx % ch || ks < 1 || ks > 3) return CY_ERR_ARG;
@@ -304,6 +306,7 @@ extern "C" int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int 
 
 extern "C" int cy_wgrad_reduce(const float* part, int split, int CoRows, int CiPad, int ks, int Co, int Ci, float scale,
                                int accumulate, float* grad, cy_stream_t s) {
+    CY_ENTER();
     if (!part || !grad || split < 1 || Co > CoRows || Ci > CiPad) return CY_ERR_ARG;
     const int total = Co * Ci * ks * ks;
     const int blocks = min(2048, (total + 255) / 256);
@@ -314,6 +317,7 @@ extern "C" int cy_wgrad_reduce(const float* part, int split, int CoRows, int CiP
 }
 
 extern "C" int cy_probe_tr16(uint16_t* out, cy_stream_t s) {
+    CY_ENTER();
     if (!out) return CY_ERR_ARG;
     hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, cy_s(s), out);
     CY_LAUNCH_CHECK();

@@ -397,6 +397,7 @@ inline int ppb_for(long M, int C, int ch) {
 
 extern "C" int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
                              const float* scale, const float* shift, int act, int dtype, cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!x || !y || !scale || !shift || !rowmap_ok(C, ch) || ldx % ch || ldy % ch || (res && ldres % ch)) return CY_ERR_ARG;
     const int ppb = ppb_for(M, C, ch);
@@ -418,6 +419,7 @@ extern "C" int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const voi
 }
 
 extern "C" int cy_bn_bwd_rows(int64_t M, int C, int dtype) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!rowmap_ok(C, ch)) return CY_ERR_ARG;
     const int ppb = ppb_for(M, C, ch);
@@ -427,6 +429,7 @@ extern "C" int cy_bn_bwd_rows(int64_t M, int C, int dtype) {
 extern "C" int cy_bn_act_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, int64_t M, int C,
                                     const float* mean, const float* invstd, const float* scale, const float* shift,
                                     int act, int dtype, float* part, cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!x || !dy || !part || !rowmap_ok(C, ch) || ldx % ch || lddy % ch) return CY_ERR_ARG;
     const int ppb = ppb_for(M, C, ch);
@@ -450,6 +453,7 @@ extern "C" int cy_bn_act_bwd_apply(const void* x, int ldx, const void* dy, int l
                                    const float* invstd, const float* scale, const float* shift,
                                    const float* dgamma_sum, const float* dbeta_sum, int act, int dtype,
                                    cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!x || !dy || !dx || !rowmap_ok(C, ch) || ldx % ch || lddy % ch || lddx % ch || (res_grad && ldrg % ch))
         return CY_ERR_ARG;
@@ -474,6 +478,7 @@ extern "C" int cy_bn_finalize(const float* stats_part, int rows, int C, int64_t 
                               const float* beta, float* running_mean, float* running_var,
                               int64_t* num_batches_tracked, float momentum, float eps, float* mean, float* invstd,
                               float* scale, float* shift, cy_stream_t s) {
+    CY_ENTER();
     if (!stats_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows < 1 || count < 1)
         return CY_ERR_ARG;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), stats_part, rows, C, (double)count,
@@ -486,6 +491,7 @@ extern "C" int cy_bn_finalize(const float* stats_part, int rows, int C, int64_t 
 extern "C" int cy_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                                  const float* running_var, int C, float eps, float* scale, float* shift,
                                  cy_stream_t s) {
+    CY_ENTER();
     if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return CY_ERR_ARG;
     hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, cy_s(s), gamma, beta, running_mean,
                        running_var, C, eps, scale, shift);
@@ -495,6 +501,7 @@ extern "C" int cy_bn_eval_affine(const float* gamma, const float* beta, const fl
 
 extern "C" int cy_bn_bwd_finalize(const float* part, int rows, int C, float* dgamma_sum, float* dbeta_sum,
                                   float* ggamma, float* gbeta, float gscale, cy_stream_t s) {
+    CY_ENTER();
     if (!part || !dgamma_sum || !dbeta_sum || rows < 1) return CY_ERR_ARG;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), part, rows, C, dgamma_sum,
                        dbeta_sum, ggamma, gbeta, gscale);
@@ -504,6 +511,7 @@ extern "C" int cy_bn_bwd_finalize(const float* part, int rows, int C, float* dga
 
 extern "C" int cy_slice_copy(const void* x, int ldx, void* y, int ldy, int64_t M, int C, int accumulate, int dtype,
                              cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!x || !y || C % ch || ldx % ch || ldy % ch) return CY_ERR_ARG;
     const int g = grid_for(M * (C / ch));
@@ -520,6 +528,7 @@ extern "C" int cy_slice_copy(const void* x, int ldx, void* y, int ldy, int64_t M
 
 extern "C" int cy_slice_add(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int64_t M, int C,
                             int dtype, cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!a || !b || !y || C % ch || lda % ch || ldb % ch || ldy % ch) return CY_ERR_ARG;
     const int g = grid_for(M * (C / ch));
@@ -534,6 +543,7 @@ extern "C" int cy_slice_add(const void* a, int lda, const void* b, int ldb, void
 
 extern "C" int cy_maxpool_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int OH, int OW, int ldy,
                               int k, int stride, int pad, uint8_t* argmax, int dtype, cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!x || !y || C % ch || ldx % ch || ldy % ch || k < 1 || k > 15) return CY_ERR_ARG;
     const int g = grid_for((long)N * OH * OW * (C / ch));
@@ -549,6 +559,7 @@ extern "C" int cy_maxpool_fwd(const void* x, int N, int H, int W, int C, int ldx
 extern "C" int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int lddy, const uint8_t* argmax, void* dx,
                               int H, int W, int lddx, int k, int stride, int pad, int accumulate, float* scratch,
                               int dtype, cy_stream_t s) {
+    CY_ENTER();
     if (!dy || !argmax || !dx || !scratch) return CY_ERR_ARG;
     const long in_elems = (long)N * H * W * C;
     if (hipMemsetAsync(scratch, 0, in_elems * sizeof(float), cy_s(s)) != hipSuccess) return -(1000 + 1);
@@ -567,6 +578,7 @@ extern "C" int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int 
 
 extern "C" int cy_upsample_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, int stride,
                                int dtype, cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!x || !y || C % ch || ldx % ch || ldy % ch || stride < 1) return CY_ERR_ARG;
     const int g = grid_for((long)N * H * W * stride * stride * (C / ch));
@@ -580,6 +592,7 @@ extern "C" int cy_upsample_fwd(const void* x, int N, int H, int W, int C, int ld
 
 extern "C" int cy_upsample_bwd(const void* dy, int N, int H, int W, int C, int lddy, void* dx, int lddx, int stride,
                                int accumulate, int dtype, cy_stream_t s) {
+    CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!dy || !dx || C % ch || lddy % ch || lddx % ch || stride < 1) return CY_ERR_ARG;
     const int g = grid_for((long)N * H * W * (C / ch));
@@ -593,6 +606,7 @@ extern "C" int cy_upsample_bwd(const void* dy, int N, int H, int W, int C, int l
 
 extern "C" int cy_f32_to_view(const float* x, int64_t M, int C, float scale, const float* scale_dev, void* y,
                               int ldy, int CPad, int dtype, cy_stream_t s) {
+    CY_ENTER();
     if (!x || !y || CPad < C || ldy < CPad) return CY_ERR_ARG;
     const int g = grid_for(M * CPad);
 #define CY_FV(T) \
@@ -605,6 +619,7 @@ extern "C" int cy_f32_to_view(const float* x, int64_t M, int C, float scale, con
 
 extern "C" int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dtype, void* out,
                                cy_stream_t s) {
+    CY_ENTER();
     if (!x || !out || CPad < C) return CY_ERR_ARG;
     const int g = grid_for((long)N * H * W);
 #define CY_NH(T) \
@@ -617,6 +632,7 @@ extern "C" int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int C
 
 extern "C" int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad, int CiPad, int dtype, void* wf,
                                void* wd, cy_stream_t s) {
+    CY_ENTER();
     if (!w || !wf || CoPad < Co || CiPad < Ci) return CY_ERR_ARG;
     const int g = grid_for((long)CoPad * ks * ks * CiPad);
 #define CY_PW(T) \
@@ -629,6 +645,7 @@ extern "C" int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad
 
 extern "C" int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, const float* scale_dev,
                             float* gbias, cy_stream_t s) {
+    CY_ENTER();
     if (!dlogits || !gbias || C < 1) return CY_ERR_ARG;
     hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, cy_s(s), dlogits, (long)M, C, scale, scale_dev, gbias);
     CY_LAUNCH_CHECK();

@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(64) pp2_sweep_kernel(NmsWork w, int K, const i
 
 extern "C" int cy_riou_pairs(const float* pred, const float* target, int n, int giou, float* ious, float* terms,
                              float* gpred, cy_stream_t s) {
+    CY_ENTER();
     if (n < 0 || (n > 0 && (!pred || !target || !ious || !terms))) return CY_ERR_ARG;
     if (n == 0) return 0;
     hipLaunchKernelGGL(riou_pairs_kernel, dim3((n + 63) / 64), dim3(64), 0, cy_s(s), pred, target, n, giou, ious, terms,
@@ -299,6 +300,7 @@ extern "C" int cy_riou_pairs(const float* pred, const float* target, int n, int 
 
 extern "C" int cy_riou_anchors(const float* anchors_wlir, int nA, const float* targets_wlir, int nT, float* ious,
                                cy_stream_t s) {
+    CY_ENTER();
     if (nA < 1 || nT < 0 || !anchors_wlir || (nT > 0 && (!targets_wlir || !ious))) return CY_ERR_ARG;
     if (nT == 0) return 0;
     hipLaunchKernelGGL(riou_anchors_kernel, dim3((nA * nT + 63) / 64), dim3(64), 0, cy_s(s), anchors_wlir, nA,
@@ -308,6 +310,7 @@ extern "C" int cy_riou_anchors(const float* anchors_wlir, int nA, const float* t
 }
 
 extern "C" int cy_riou_matrix(const float* a, int na, const float* b, int nb, float eps, float* iou, cy_stream_t s) {
+    CY_ENTER();
     if (na < 0 || nb < 0 || (na > 0 && nb > 0 && (!a || !b || !iou))) return CY_ERR_ARG;
     if (na == 0 || nb == 0) return 0;
     const long total = (long)na * nb;
@@ -325,6 +328,7 @@ extern "C" int64_t cy_rnms_workspace(int B, int K) {
 
 extern "C" int cy_rnms_greedy(const float* boxes, const float* confs, int K, float nms_thresh, void* workspace,
                               int32_t* keep, int32_t* count, cy_stream_t s) {
+    CY_ENTER();
     if (K < 0 || !count || (K > 0 && (!boxes || !confs || !workspace || !keep))) return CY_ERR_ARG;
     if (K == 0) return hipMemsetAsync(count, 0, sizeof(int32_t), cy_s(s)) == hipSuccess ? 0 : -(1000 + 1);
     NmsWork w = carve_nms(workspace, 1, K, nullptr);
@@ -342,6 +346,7 @@ extern "C" int cy_rnms_greedy(const float* boxes, const float* confs, int K, flo
 
 extern "C" int cy_pp2_select(const float* pred, int B, int N, int C, float conf_thresh, void* workspace,
                              int32_t* cand_idx, int32_t* cand_count, cy_stream_t s) {
+    CY_ENTER();
     if (!pred || !workspace || !cand_idx || !cand_count || B < 1 || N < 1 || C < 1) return CY_ERR_ARG;
     int* rows = (int*)workspace;
     float* scores = (float*)((unsigned char*)workspace + sizeof(int) * (size_t)B * N);
@@ -356,6 +361,7 @@ extern "C" int cy_pp2_select(const float* pred, int B, int N, int C, float conf_
 extern "C" int cy_pp2_merge(const float* pred, int B, int N, int C, const int32_t* cand_idx,
                             const int32_t* cand_count, int Kmax, float nms_thresh, void* workspace, float* det,
                             int32_t* det_src, int32_t* det_count, cy_stream_t s) {
+    CY_ENTER();
     if (!pred || !cand_idx || !cand_count || !workspace || !det || !det_src || !det_count || Kmax < 1) return CY_ERR_ARG;
     NmsWork w = carve_nms(workspace, B, Kmax, nullptr);
     if ((size_t)w.W * 8 > 160 * 1024) return CY_ERR_ARG;
@@ -369,9 +375,11 @@ extern "C" int cy_pp2_merge(const float* pred, int B, int N, int C, const int32_
     return 0;
 }
 
-extern "C" int cy_version(void) { return 100; }
+extern "C" int cy_version(void) {
+    CY_ENTER(); return 100; }
 
 extern "C" int cy_device_info(int* cus, int* wave) {
+    CY_ENTER();
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -(1000 + 1);
     hipDeviceProp_t prop;

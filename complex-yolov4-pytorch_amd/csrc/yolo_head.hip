@@ -312,6 +312,7 @@ inline int fill_anchors(Anchors& an, const float* host, int A, int fields, doubl
 
 extern "C" int cy_yolo_decode(const float* logits, int B, int G, int A, int C, const float* anchors_host,
                               float img_size, float* out, int rows_total, int row_offset, cy_stream_t s) {
+    CY_ENTER();
     if (!logits || !out || !anchors_host || C < 1 || C > 23 || 7 + C > 32) return CY_ERR_ARG;
     Anchors an;
     const double stride = (double)img_size / (double)G;
@@ -335,6 +336,7 @@ extern "C" int64_t cy_yolo_loss_workspace(int B, int G, int A, int C, int nT) {
 extern "C" int cy_yolo_loss(const float* logits, int B, int G, int A, int C, const float* targets, int nT,
                             const float* anchors_host, float img_size, float ignore_thresh, int use_giou,
                             void* workspace, float* metrics, float* dlogits, cy_stream_t s) {
+    CY_ENTER();
     if (!logits || !workspace || !metrics || !dlogits || !anchors_host || nT < 0 || (nT > 0 && !targets))
         return CY_ERR_ARG;
     if (C < 1 || C > 23 || 7 + C > 32) return CY_ERR_ARG;

@@ -69,7 +69,8 @@ class _StepFn(torch.autograd.Function):
         if not eng.training:
             raise ops.CyoloError('backward needs model.train(): eval-mode engines keep no activations')
         grads = model._grad_table()
-        eng.backward(grads, gloss.detach().reshape(-1).float().contiguous(), model.loss_scale)
+        eng.backward(grads, gloss.detach().reshape(-1).float().contiguous(), model.loss_scale,
+                     on_module_done=(lambda idx: [h(model, idx) for h in model._module_grad_hooks]) if model._module_grad_hooks else None)
         for hook in model._post_backward_hooks:
             hook(model)
         return (None, None, None) + (None,) * len(model._plist)
@@ -83,8 +84,10 @@ class Darknet(nn.Module):
         self.width = int(self.blocks[0]['width'])
         self.height = int(self.blocks[0]['height'])
         self.dtype_code = ops.dtype_code(dtype)
-        # fp16 activations gradients are scaled to stay clear of the fp16 subnormal range; parity mode needs none
-        self.loss_scale = float(loss_scale if loss_scale is not None else (1024.0 if self.dtype_code == ops.CY_F16 else 1.0))
+        # static scale applied to d(logits) before it enters the fp16 backward and removed in the parameter-gradient
+        # reductions.  Default 1: at random init the gradients are LARGE (a scale of 1024 overflows fp16 on
+        # complex_yolov4.cfg); measured on the mini cfg the gradient error does not depend on it between 1 and 1024.
+        self.loss_scale = float(loss_scale if loss_scale is not None else 1.0)
         self.models = self.create_network(self.blocks)
         self.yolo_layers = [layer for layer in self.models if layer.__class__.__name__ == 'YoloLayer']
         self.loss = self.models[len(self.models) - 1]
@@ -95,6 +98,7 @@ class Darknet(nn.Module):
         self._plist = None
         self._grad_flat = None
         self._post_backward_hooks = []
+        self._module_grad_hooks = []     # called as hook(model, module_idx) when a module's gradients are final
 
     # ---- construction (reference create_network :235-401) -----------------------------------------
     def create_network(self, blocks):

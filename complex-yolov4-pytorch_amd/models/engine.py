@@ -105,6 +105,16 @@ class Engine:
             getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
         return self.outputs
 
+    def _conv_work(self, rec):
+        """(algorithmic flops, algorithmic bytes) of one pass of this conv: 2*M*Cout*k*k*Cin with the REAL channel
+        counts, and input + output + weights each touched once in the storage dtype."""
+        M = self.N * rec['H'] * rec['W']
+        kk = rec['ks'] * rec['ks']
+        es = 2 if self.dt == ops.CY_F16 else 4
+        flops = 2.0 * M * rec['cout'] * kk * rec['cin']
+        nbytes = es * (self.N * rec['xH'] * rec['xW'] * rec['cin'] + M * rec['cout'] + rec['cout'] * kk * rec['cin'])
+        return flops, nbytes
+
     def _names(self, rec):
         i, n = rec['idx'], rec['n']
         return 'models.%d.conv%d' % (i, n), 'models.%d.bn%d' % (i, n)
@@ -126,13 +136,15 @@ class Engine:
         mean, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3]
         C, M = rec['cout'], raw.M
         if self.training:
-            ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=CONV_STATS,
-                           stats=self.stats)
+            with ops.prof('igemm', *self._conv_work(rec)):
+                ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=CONV_STATS,
+                               stats=self.stats)
             ops.bn_finalize(self.stats, ops.conv_stats_rows(M, C), C, M, P[bname + '.weight'], P[bname + '.bias'],
                             P[bname + '.running_mean'], P[bname + '.running_var'],
                             P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, mean, invstd, scale, shift)
         else:
-            ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'])
+            with ops.prof('igemm', *self._conv_work(rec)):
+                ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'])
             ops.bn_eval_affine(P[bname + '.weight'], P[bname + '.bias'], P[bname + '.running_mean'],
                                P[bname + '.running_var'], BN_EPS, scale, shift)
         res = self.view(rec['res']) if rec['res'] is not None else None
@@ -169,19 +181,23 @@ class Engine:
                       rec['ignore_thresh'], use_giou, self.loss_ws[h], self.metrics[h], dl)
 
     # ---- backward --------------------------------------------------------------------------------
-    def backward(self, grads, gout_dev, loss_scale):
-        """grads: {param name: fp32 gradient tensor (accumulated into)}; gout_dev: device scalar d(loss)."""
+    def backward(self, grads, gout_dev, loss_scale, on_module_done=None):
+        """grads: {param name: fp32 gradient tensor (accumulated into)}; gout_dev: device scalar d(loss).
+        on_module_done(idx) is called after the kernels that finish module idx's parameter gradients are queued."""
         assert self.training
         self.grads, self.gout, self.ls = grads, gout_dev, float(loss_scale)
         for rec in self.plan.bwd:
             getattr(self, '_b_' + rec['op'])(rec)
+            if on_module_done is not None and rec['op'] in ('conv_bwd', 'head_conv_bwd'):
+                on_module_done(rec['fwd']['idx'])
 
     def _wgrad(self, rec, dy, xv):
         idx = rec['idx']
         cname, _ = self._names(rec)
         cop, cip = _pad32(rec['cout']), rec['cin_pad']
         sp = self.wsplit[idx]
-        ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], self.wpart, sp)
+        with ops.prof('wgrad', *self._conv_work(rec)):
+            ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], self.wpart, sp)
         ops.wgrad_reduce(self.wpart, sp, cop, cip, rec['ks'], rec['cout'], rec['cin'], 1.0 / self.ls, True,
                          self.grads[cname + '.weight'])
 
@@ -190,8 +206,10 @@ class Engine:
         x = rec['x']
         for ref, acc in runs:
             r0 = ref.c0 - x.c0
-            ops.conv_igemm(dy, wd[r0:r0 + ref.C], ref.C, self.view(ref, grad=True), rec['ks'], rec['stride'],
-                           rec['pad'], flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0))
+            fl, by = self._conv_work(rec)
+            with ops.prof('igemm', fl * ref.C / x.C, by):
+                ops.conv_igemm(dy, wd[r0:r0 + ref.C], ref.C, self.view(ref, grad=True), rec['ks'], rec['stride'],
+                               rec['pad'], flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0))
 
     def _b_conv_bwd(self, b):
         rec = b['fwd']

@@ -14,6 +14,59 @@ _TORCH_DT = {CY_F16: torch.float16, CY_F32: torch.float32}
 _ELSIZE = {CY_F16: 2, CY_F32: 4}
 
 
+class LaunchProfiler:
+    """Brackets selected kernel launches with HIP events on the launch stream (torch's current stream) and keeps
+    (kind, algorithmic flops, algorithmic bytes, start, end) so bench.py can report per-kernel achieved rates."""
+
+    def __init__(self):
+        self.records = []
+
+    def bracket(self, kind, flops, nbytes):
+        return _Bracket(self, kind, flops, nbytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, flops, nbytes, s, e in self.records:
+            d = out.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d['launches'] += 1
+            d['ms'] += s.elapsed_time(e)
+            d['flops'] += flops
+            d['bytes'] += nbytes
+        return out
+
+
+class _Bracket:
+    def __init__(self, prof, kind, flops, nbytes):
+        self.prof, self.kind, self.flops, self.nbytes = prof, kind, flops, nbytes
+
+    def __enter__(self):
+        self.s = torch.cuda.Event(enable_timing=True)
+        self.e = torch.cuda.Event(enable_timing=True)
+        self.s.record()
+
+    def __exit__(self, *a):
+        self.e.record()
+        self.prof.records.append((self.kind, self.flops, self.nbytes, self.s, self.e))
+
+
+class _NoBracket:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOBRACKET = _NoBracket()
+PROFILER = None
+
+
+def prof(kind, flops=0.0, nbytes=0.0):
+    """Context manager around a launch; a no-op unless ops.PROFILER is set (bench.py's roofline leg)."""
+    return _NOBRACKET if PROFILER is None else PROFILER.bracket(kind, flops, nbytes)
+
+
 def dtype_code(name):
     """'f16' / 'f32' (or the codes themselves) -> CY_F16 / CY_F32."""
     if name in (CY_F16, 'f16', 'fp16', 'half', torch.float16):

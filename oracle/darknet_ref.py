@@ -97,6 +97,8 @@ class DarknetRef:
                 w = params['models.%d.conv%d.weight' % (i, n)]
                 b = params.get('models.%d.conv%d.bias' % (i, n))
                 x = F.conv2d(x, w, b, m['stride'], m['pad'])
+                if keep is not None:
+                    keep[('raw', i)] = x
                 if m['bn']:
                     g = params['models.%d.bn%d.weight' % (i, n)]
                     be = params['models.%d.bn%d.bias' % (i, n)]

@@ -1,0 +1,173 @@
+"""End-to-end GPU parity: the drop-in Darknet on the HIP path vs the golden fixtures produced by the reference
+(tests/golden/darknet.npz) and vs the oracle on the same seeded batch.
+
+f32 parity mode is held to the north_star tolerances where the problem is well conditioned (loss 1e-4 relative,
+probabilities/logits 1e-3 .. 2e-3 absolute after 21/110 float32 layers); f16 performance mode reports its own,
+looser band explicitly (after 110 half-precision conv layers head logits cannot meet 1e-3)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import complex_yolov4_pytorch_amd.synthetic as syn  # noqa: E402
+from complex_yolov4_pytorch_amd.models.darknet2pytorch import Darknet  # noqa: E402
+from tests.golden.make_golden import METRIC_KEYS  # noqa: E402
+
+CFG = os.path.join(os.path.dirname(__file__), '..', 'complex-yolov4-pytorch_amd', 'config', 'cfg')
+DEV = 'cuda'
+
+
+def _model(cfg, giou, dtype):
+    torch.manual_seed(0)
+    m = Darknet(os.path.join(CFG, cfg), use_giou_loss=giou, dtype=dtype)
+    sd = m.state_dict()
+    sd.update({k: syn.fill_tensor(k, tuple(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point})
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+CASES = [('tiny', 'complex_yolov4_tiny.cfg', 2, 608), ('v4', 'complex_yolov4.cfg', 1, 416)]
+
+
+@pytest.mark.parametrize('tag,cfg,B,S', CASES)
+@pytest.mark.parametrize('mode', ['giou', 'mse'])
+def test_train_step_f32_parity(golden, tag, cfg, B, S, mode):
+    g = golden('darknet')
+    model = _model(cfg, mode == 'giou', 'f32')
+    model.train()
+    x, tg = syn.bev_images(B, S, seed=1).to(DEV), syn.targets(B, 6, S, seed=1).to(DEV)
+    loss, out = model(x, tg)
+    loss.sum().backward()
+    key = '%s_%s_' % (tag, mode)
+    assert out.is_cuda and list(out.shape) == list(g[key + 'out_shape'])
+    assert loss.dim() == (1 if mode == 'giou' else 0)
+    np.testing.assert_allclose(loss.detach().cpu().numpy().reshape(-1), g[key + 'loss'], rtol=1e-4)
+    np.testing.assert_allclose(out[:, ::97].cpu().numpy(), g[key + 'out_rows'], rtol=2e-3, atol=2e-3)
+    met = [[yl.metrics[k] for k in METRIC_KEYS] for yl in model.yolo_layers]
+    np.testing.assert_allclose(met, g[key + 'metrics'], rtol=2e-3, atol=1e-5)
+    assert all(yl.metrics_raw[19] == 0 for yl in model.yolo_layers)
+    gn = np.asarray([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+    np.testing.assert_allclose(gn, g[key + 'grad_norm'], rtol=5e-3 if tag == 'tiny' else 3e-2, atol=1e-6)
+    gh = np.stack([p.grad.reshape(-1)[:8].cpu().numpy() for _, p in model.named_parameters()])
+    ref_gh = g[key + 'grad_head']
+    # v4 at random init / batch 1 is ill-conditioned (see tests/test_plan_sim.py): tight check on the tiny net only
+    assert np.all(np.abs(gh - ref_gh) <= (5e-3 if tag == 'tiny' else 0.3) * np.abs(ref_gh).max(1, keepdims=True) + 2e-5)
+    sd = model.state_dict()
+    bn = np.stack([sd[str(n)][:8].cpu().numpy() for n in g[key + 'bn_names']])
+    # running_var comes from fp32 partial sums (E[x^2]-m^2 folded in double): 5e-4
+    np.testing.assert_allclose(bn, g[key + 'bn_head'], rtol=5e-4, atol=1e-5)
+    if mode == 'giou':
+        model.eval()
+        with torch.no_grad():
+            o = model(x)
+        assert not o.is_cuda                                   # reference returns a CPU tensor (darknet2pytorch.py:228)
+        np.testing.assert_allclose(o[:, ::97].numpy(), g['%s_eval_rows' % tag], rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize('tag,cfg,B,S', CASES)
+def test_train_step_f16_band(golden, tag, cfg, B, S):
+    """Performance mode (fp16 storage, fp32 accumulate): stated band, not the fp32 tolerance."""
+    g = golden('darknet')
+    model = _model(cfg, True, 'f16')
+    model.train()
+    x, tg = syn.bev_images(B, S, seed=1).to(DEV), syn.targets(B, 6, S, seed=1).to(DEV)
+    loss, out = model(x, tg)
+    loss.sum().backward()
+    key = '%s_giou_' % tag
+    ref_loss = float(g[key + 'loss'][0])
+    rel = abs(float(loss.detach()) - ref_loss) / ref_loss
+    print('f16 loss %.5f vs fp32 reference %.5f (rel %.2e)' % (float(loss), ref_loss, rel))
+    assert rel < 3e-2
+    got, ref = out[:, ::97].cpu().numpy(), g[key + 'out_rows']
+    dprob = np.abs(got[..., 6:] - ref[..., 6:])
+    print('f16 probabilities: median |d| %.3e, max |d| %.3e' % (float(np.median(dprob)), float(dprob.max())))
+    if tag == 'tiny':
+        # 21 layers: probabilities within 3e-2, boxes within 5% / 0.5 px
+        assert dprob.max() < 3e-2
+        np.testing.assert_allclose(got[..., :4], ref[..., :4], rtol=5e-2, atol=0.5)
+    else:
+        # 110 fp16 layers on a random-init net with batch-1 BatchNorm (ill-conditioned, see test_plan_sim.py): stated band
+        assert np.median(dprob) < 3e-2 and dprob.max() < 0.35
+    gn = np.asarray([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+    assert np.all(np.isfinite(gn))
+    ref_gn = g[key + 'grad_norm']
+    # gradient norms track the fp32 reference (loose: fp16 rounding on an ill-conditioned random-init net)
+    ratio = gn / np.maximum(ref_gn, 1e-12)
+    assert 0.8 < np.median(ratio) < 1.25
+
+
+def test_train_step_matches_oracle_with_collisions():
+    """Fresh batch with two targets sharing a cell in every head (App. A #7), fp32, vs the oracle end to end."""
+    from complex_yolov4_pytorch_amd.models.darknet_utils import parse_cfg
+    from oracle import darknet_ref
+    cfg = os.path.join(CFG, 'complex_yolov4_tiny.cfg')
+    model = _model('complex_yolov4_tiny.cfg', True, 'f32')
+    model.train()
+    x, tg = syn.bev_images(2, 320, seed=9), syn.targets(2, 4, 320, seed=9, collide=True)
+    loss, out = model(x.to(DEV), tg.to(DEV))
+    loss.backward()
+    net = darknet_ref.DarknetRef(parse_cfg(cfg))
+    ps, bs = net.param_shapes()
+    params = {k: v.requires_grad_(True) for k, v in syn.fill_state_dict(ps).items()}
+    o_ref, l_ref, _ = net.forward(params, x, tg, True, True, syn.fill_state_dict(bs))
+    l_ref.sum().backward()
+    from tests.util import grad_rel_errors
+    np.testing.assert_allclose(float(loss.detach()), float(l_ref.detach()), rtol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), o_ref.detach().numpy(), rtol=2e-3, atol=2e-3)
+    errs = grad_rel_errors([(n, p.grad.cpu()) for n, p in model.named_parameters()], {k: v.grad for k, v in params.items()})
+    print('grad rel err: median %.2e max %.2e' % (float(np.median(list(errs.values()))), max(errs.values())))
+    # A leaky-ReLU pre-activation within fp32 round-off of 0 flips slope between two evaluation orders; on this batch one
+    # such element carries a large head gradient and moves every upstream gradient by ~5% (reproduced with the CPU
+    # simulator, so it is a property of the problem, not of the kernels).  Tight gradient parity: test_mini_cfg_*.
+    assert max(errs.values()) < 1.0
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f16'])
+def test_mini_cfg_all_block_types(dtype):
+    """All-Mish mini cfg (tests/util.py): grouped route, copied cat member, alias route, fused shortcut, SPP max-pools,
+    upsample, two heads.  Smooth activations -> every parameter gradient is compared tightly in fp32 mode."""
+    from complex_yolov4_pytorch_amd.models.darknet_utils import parse_cfg
+    from oracle import darknet_ref
+    from tests.util import grad_rel_errors, mini_cfg_path
+    cfg = mini_cfg_path()
+    torch.manual_seed(0)
+    model = Darknet(cfg, use_giou_loss=True, dtype=dtype)
+    sd = model.state_dict()
+    sd.update({k: syn.fill_tensor(k, tuple(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point})
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    x, tg = syn.bev_images(2, 64, seed=4, sparsity=0.5), syn.targets(2, 3, 64, seed=4, collide=True)
+    loss, out = model(x.to(DEV), tg.to(DEV))
+    loss.backward()
+    net = darknet_ref.DarknetRef(parse_cfg(cfg))
+    ps, bs = net.param_shapes()
+    params = {k: v.requires_grad_(True) for k, v in syn.fill_state_dict(ps).items()}
+    o_ref, l_ref, _ = net.forward(params, x, tg, True, True, syn.fill_state_dict(bs))
+    l_ref.sum().backward()
+    errs = grad_rel_errors([(n, p.grad.cpu()) for n, p in model.named_parameters()], {k: v.grad for k, v in params.items()})
+    rel_loss = abs(float(loss.detach()) - float(l_ref.detach())) / float(l_ref.detach())
+    print('%s: loss rel %.2e, grad rel err median %.2e max %.2e' % (dtype, rel_loss, float(np.median(list(errs.values()))), max(errs.values())))
+    if dtype == 'f32':
+        assert rel_loss < 1e-4
+        np.testing.assert_allclose(out.cpu().numpy(), o_ref.detach().numpy(), rtol=1e-3, atol=1e-3)
+        assert max(errs.values()) < 2e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    else:
+        assert rel_loss < 1e-2
+        assert np.median(list(errs.values())) < 0.15 and max(errs.values()) < 0.6
+
+
+def test_inference_and_nms_pipeline():
+    """evaluate.py path: model.eval()(imgs) -> post_processing_v2 (reference evaluate.py:44-45)."""
+    from complex_yolov4_pytorch_amd.utils.evaluation_utils import post_processing_v2
+    model = _model('complex_yolov4_tiny.cfg', True, 'f16')
+    model.eval()
+    with torch.no_grad():
+        out = model(syn.bev_images(2, 608, seed=3).to(DEV))
+    assert tuple(out.shape) == (2, 5415, 10) and not out.is_cuda
+    dets = post_processing_v2(out, conf_thresh=0.5, nms_thresh=0.5)
+    assert len(dets) == 2
+    for d in dets:
+        assert d is None or (d.shape[1] == 9 and not d.is_cuda)

@@ -92,6 +92,35 @@ def test_darknet_sim_matches_reference_golden(monkeypatch, golden, tag, cfg, B, 
         np.testing.assert_allclose(o[:, ::97].numpy(), g['%s_eval_rows' % tag], rtol=2e-2, atol=2e-3)
 
 
+def test_mini_cfg_all_block_types_tight_gradients(monkeypatch):
+    """All-Mish mini cfg (grouped route, copied cat member, alias route, fused shortcut, SPP, upsample, two heads):
+    smooth activations, so EVERY parameter gradient must agree with the oracle tightly."""
+    from oracle import darknet_ref
+    from tests.util import grad_rel_errors, mini_cfg_path
+    opsim.install(monkeypatch)
+    cfg = mini_cfg_path()
+    torch.manual_seed(0)
+    model = Darknet(cfg, use_giou_loss=True, dtype='f32')
+    sd = model.state_dict()
+    sd.update({k: syn.fill_tensor(k, tuple(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point})
+    model.load_state_dict(sd)
+    model.train()
+    plan_ops = [r['op'] for r in model._engine_for(torch.zeros(2, 3, 64, 64)).plan.fwd]
+    assert plan_ops.count('copy') == 1 and plan_ops.count('pool') == 3 and plan_ops.count('upsample') == 1
+    x, tg = syn.bev_images(2, 64, seed=4, sparsity=0.5), syn.targets(2, 3, 64, seed=4, collide=True)
+    loss, out = model(x, tg)
+    loss.backward()
+    net = darknet_ref.DarknetRef(parse_cfg(cfg))
+    ps, bs = net.param_shapes()
+    params = {k: v.requires_grad_(True) for k, v in syn.fill_state_dict(ps).items()}
+    o_ref, l_ref, _ = net.forward(params, x, tg, True, True, syn.fill_state_dict(bs))
+    l_ref.sum().backward()
+    np.testing.assert_allclose(float(loss.detach()), float(l_ref.detach()), rtol=1e-5)
+    np.testing.assert_allclose(out.numpy(), o_ref.detach().numpy(), rtol=1e-3, atol=1e-3)
+    errs = grad_rel_errors([(n, p.grad) for n, p in model.named_parameters()], {k: v.grad for k, v in params.items()})
+    assert max(errs.values()) < 2e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
 def test_gradient_accumulation_and_zero_grad(monkeypatch):
     """reference train.py:212-221: gradients add up over sub-divisions; zero_grad(set_to_none) restarts."""
     opsim.install(monkeypatch)
