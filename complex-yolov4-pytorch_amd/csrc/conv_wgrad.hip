@@ -242,20 +242,33 @@ int dispatch(const WgradParams& p, int split, hipStream_t s) {
     return CY_ERR_ARG;
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int split, int CoRows, int CiPad, int ks, int Co,
-                                    int Ci, float scale, int accumulate, float* __restrict__ grad) {
-    const int total = Co * Ci * ks * ks;
-    const int ncols = ks * ks * CiPad;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        // idx walks the slab-friendly order (co, tap, ci) so that reads are coalesced
-        const int ci = idx % Ci;
-        const int t = idx / Ci;
-        const int tap = t % (ks * ks), co = t / (ks * ks);
-        const size_t src = (size_t)co * ncols + tap * CiPad + ci;
-        float s = 0.f;
-        for (int sp = 0; sp < split; ++sp) s += part[(size_t)sp * CoRows * ncols + src];
-        const size_t dst = ((size_t)co * Ci + ci) * ks * ks + tap;
-        grad[dst] = scale * s + (accumulate ? grad[dst] : 0.f);
+// Fold the split-K slabs: block = 64 consecutive output elements x 4 waves striding over the slabs (every wave
+// reads 256 contiguous bytes of one slab per step), combined through LDS; then scatter into the OIHW gradient.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int split, int CoRows, int CiPad,
+                                                          int ks, int Co, int Ci, float scale, int accumulate,
+                                                          float* __restrict__ grad) {
+    __shared__ float red[4][64];
+    const int kk = ks * ks;
+    const long total = (long)Co * kk * Ci;   // walked in slab order (co, tap, ci)
+    const int ncols = kk * CiPad;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    size_t src = 0, dst = 0;
+    if (idx < total) {
+        const int ci = (int)(idx % Ci);
+        const long t = idx / Ci;
+        const int tap = (int)(t % kk), co = (int)(t / kk);
+        src = (size_t)co * ncols + tap * CiPad + ci;
+        dst = ((size_t)co * Ci + ci) * kk + tap;
+        const size_t slab = (size_t)CoRows * ncols;
+        for (int sp = w; sp < split; sp += 4) s += part[(size_t)sp * slab + src];
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && idx < total) {
+        const float v = scale * (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+        grad[dst] = v + (accumulate ? grad[dst] : 0.f);
     }
 }
 
@@ -278,8 +291,8 @@ extern "C" int cy_conv_wgrad_split(int M, int Co, int Ci, int ks) {
     CY_ENTER();
     const int ncols = ks * ks * Ci;
     const long tiles = (long)((Co + tile_of(Co) - 1) / tile_of(Co)) * ((ncols + tile_of(ncols) - 1) / tile_of(ncols));
-    long split = (1024 + tiles - 1) / tiles;
-    const long max_by_work = (M + 255) / 256;  // at least 4 K steps per block
+    long split = (768 + tiles - 1) / tiles;
+    const long max_by_work = (M + 511) / 512;  // at least 8 K steps per block
     if (split > max_by_work) split = max_by_work;
     const long slab = (long)Co * ncols * 4;
     while (split > 1 && split * slab > (256L << 20)) --split;
@@ -308,10 +321,9 @@ extern "C" int cy_wgrad_reduce(const float* part, int split, int CoRows, int CiP
                                int accumulate, float* grad, cy_stream_t s) {
     CY_ENTER();
     if (!part || !grad || split < 1 || Co > CoRows || Ci > CiPad) return CY_ERR_ARG;
-    const int total = Co * Ci * ks * ks;
-    const int blocks = min(2048, (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, cy_s(s), part, split, CoRows, CiPad, ks, Co, Ci,
-                       scale, accumulate, grad);
+    const long total = (long)Co * Ci * ks * ks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, cy_s(s), part, split, CoRows,
+                       CiPad, ks, Co, Ci, scale, accumulate, grad);
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -137,38 +137,61 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* rmean,
-                                   float* rvar, long long* nbt, float momentum, float eps, float* mean, float* invstd,
-                                   float* scale, float* shift) {
-    // one wave per channel: lanes stride over the partial rows, accumulate in double
-    const int c = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+// Column sums of a [rows][2][C] float partial table, coalesced: lanes run over channels, the 4 waves of a block and
+// the blocks of grid.y run over rows.  Writes double chunk sums to chunk_out[chunk][2][C].
+constexpr int CY_COLSUM_CHUNKS = 64;
+__global__ void __launch_bounds__(256) colsum_chunk_kernel(const float* __restrict__ part, int rows, int C,
+                                                          double* __restrict__ chunk_out) {
+    __shared__ double red[4][2][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int rpc = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = r0 + w; r < r1; r += 4) {
+            s += (double)part[((size_t)r * 2) * C + c];
+            q += (double)part[((size_t)r * 2 + 1) * C + c];
+        }
+    red[w][0][threadIdx.x & 63] = s;
+    red[w][1][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const int l = threadIdx.x;
+        chunk_out[((size_t)blockIdx.y * 2) * C + c] = red[0][0][l] + red[1][0][l] + red[2][0][l] + red[3][0][l];
+        chunk_out[((size_t)blockIdx.y * 2 + 1) * C + c] = red[0][1][l] + red[1][1][l] + red[2][1][l] + red[3][1][l];
+    }
+}
+
+// finish: one wave per channel, lane k loads chunk k (nchunk <= 64), butterfly sum
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ chunks, int nchunk, int C, double count,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* rmean, float* rvar, long long* nbt, float momentum,
+                                                         float eps, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int r = lane; r < rows; r += 64) {
-        s += (double)part[((size_t)r * 2) * C + c];
-        q += (double)part[((size_t)r * 2 + 1) * C + c];
+    if (lane < nchunk) {
+        s = chunks[((size_t)lane * 2) * C + c];
+        q = chunks[((size_t)lane * 2 + 1) * C + c];
     }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
-    if (lane == 0) {
-        const double m = s / count;
-        double var = q / count - m * m;
-        if (var < 0.0) var = 0.0;
-        const float is = (float)(1.0 / sqrt(var + (double)eps));
-        mean[c] = (float)m;
-        invstd[c] = is;
-        const float sc = gamma[c] * is;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)m * sc;
-        if (rmean) {
-            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-        }
-        if (nbt && c == 0) *nbt += 1;
+    if (lane != 0) return;
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+    if (rmean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
     }
+    if (nbt && c == 0) *nbt += 1;
 }
 
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, int C,
@@ -180,24 +203,23 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C, float* dgs, float* dbs,
-                                       float* ggamma, float* gbeta, float gscale) {
-    const int c = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ chunks, int nchunk, int C,
+                                                             float* dgs, float* dbs, float* ggamma, float* gbeta,
+                                                             float gscale) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = lane; r < rows; r += 64) {
-        s1 += (double)part[((size_t)r * 2) * C + c];
-        s2 += (double)part[((size_t)r * 2 + 1) * C + c];
+    if (lane < nchunk) {
+        s1 = chunks[((size_t)lane * 2) * C + c];
+        s2 = chunks[((size_t)lane * 2 + 1) * C + c];
     }
     s1 = wave_sum_d(s1);
     s2 = wave_sum_d(s2);
-    if (lane == 0) {
-        dbs[c] = (float)s1;
-        dgs[c] = (float)s2;
-        if (gbeta) gbeta[c] += gscale * (float)s1;
-        if (ggamma) ggamma[c] += gscale * (float)s2;
-    }
+    if (lane != 0) return;
+    dbs[c] = (float)s1;
+    dgs[c] = (float)s2;
+    if (gbeta) gbeta[c] += gscale * (float)s1;
+    if (ggamma) ggamma[c] += gscale * (float)s2;
 }
 
 // ---- generic chunked element kernels (any C multiple of CH) ------------------------------------
@@ -371,6 +393,17 @@ __global__ void bias_grad_kernel(const float* __restrict__ d, long M, int C, flo
     if (threadIdx.x == 0) gbias[c] += scale * (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
+inline int colsum_chunks(int rows) {
+    const int n = (rows + 15) / 16;
+    return n < 1 ? 1 : (n > CY_COLSUM_CHUNKS ? CY_COLSUM_CHUNKS : n);
+}
+// chunk sums live behind the partial table, in the CY_BN_SCRATCH_ROWS extra rows the caller provides
+inline double* colsum_scratch(const float* part, int rows, int C) {
+    size_t off = (size_t)rows * 2 * C;
+    off = (off + 1) & ~(size_t)1;  // 8-byte alignment
+    return reinterpret_cast<double*>(const_cast<float*>(part) + off);
+}
+
 inline int grid_for(long total) {
     long b = (total + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -417,6 +450,8 @@ extern "C" int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const voi
     CY_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int cy_bn_scratch_rows(void) { return 2 * CY_COLSUM_CHUNKS + 1; }
 
 extern "C" int cy_bn_bwd_rows(int64_t M, int C, int dtype) {
     CY_ENTER();
@@ -481,9 +516,12 @@ extern "C" int cy_bn_finalize(const float* stats_part, int rows, int C, int64_t 
     CY_ENTER();
     if (!stats_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows < 1 || count < 1)
         return CY_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), stats_part, rows, C, (double)count,
-                       gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, mean,
-                       invstd, scale, shift);
+    const int nchunk = colsum_chunks(rows);
+    double* chunks = colsum_scratch(stats_part, rows, C);
+    hipLaunchKernelGGL(colsum_chunk_kernel, dim3((C + 63) / 64, nchunk), dim3(256), 0, cy_s(s), stats_part, rows, C, chunks);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), (const double*)chunks, nchunk, C,
+                       (double)count, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum,
+                       eps, mean, invstd, scale, shift);
     CY_LAUNCH_CHECK();
     return 0;
 }
@@ -503,8 +541,11 @@ extern "C" int cy_bn_bwd_finalize(const float* part, int rows, int C, float* dga
                                   float* ggamma, float* gbeta, float gscale, cy_stream_t s) {
     CY_ENTER();
     if (!part || !dgamma_sum || !dbeta_sum || rows < 1) return CY_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), part, rows, C, dgamma_sum,
-                       dbeta_sum, ggamma, gbeta, gscale);
+    const int nchunk = colsum_chunks(rows);
+    double* chunks = colsum_scratch(part, rows, C);
+    hipLaunchKernelGGL(colsum_chunk_kernel, dim3((C + 63) / 64, nchunk), dim3(256), 0, cy_s(s), part, rows, C, chunks);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), (const double*)chunks, nchunk,
+                       C, dgamma_sum, dbeta_sum, ggamma, gbeta, gscale);
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -52,10 +52,10 @@ class Engine:
             self.wd[rec['idx']] = torch.empty(cip, kk * cop, dtype=self.tdt, device=device) if training and not rec['first'] else None
             if rec['bn']:
                 self.bnvec[rec['idx']] = torch.empty(4, C, **f32)
-                max_stats = max(max_stats, ops.conv_stats_rows(M, C) * 2 * C)
+                max_stats = max(max_stats, (ops.conv_stats_rows(M, C) + ops.bn_scratch_rows()) * 2 * C)
                 max_c = max(max_c, C)
                 if training:
-                    max_bnrows = max(max_bnrows, ops.bn_bwd_rows(M, C, dt) * 2 * C)
+                    max_bnrows = max(max_bnrows, (ops.bn_bwd_rows(M, C, dt) + ops.bn_scratch_rows()) * 2 * C)
             if training:
                 sp = ops.wgrad_split(M, cop, cip, rec['ks'])
                 self.wsplit[rec['idx']] = sp

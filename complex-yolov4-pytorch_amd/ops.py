@@ -178,6 +178,11 @@ def conv_stats_rows(M, OC):
     return lib().raw('cy_conv_stats_rows')(M, OC)
 
 
+def bn_scratch_rows():
+    """Extra rows every BN partial table needs behind it (see cy_bn_scratch_rows)."""
+    return lib().raw('cy_bn_scratch_rows')()
+
+
 def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None):
     """Forward conv (or dgrad with CONV_TRANSPOSED).  g/out: Views; w: packed weight tensor."""
     _require_gpu()

@@ -62,8 +62,11 @@ int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dt
 int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out, int OH,
                   int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags, const float* bias,
                   float* stats_part, int* stats_rows_host, cy_stream_t s);
-/* Upper bound of stats rows cy_conv_igemm writes for M = N*OH*OW output pixels. */
+/* Number of stats rows cy_conv_igemm writes for M = N*OH*OW output pixels. */
 int cy_conv_stats_rows(int M, int OC);
+/* Every [rows][2][C] partial table handed to cy_bn_finalize / cy_bn_bwd_finalize must have room for this many
+ * EXTRA rows behind it: the finalisers fold the table in two coalesced stages and keep the stage-1 sums there. */
+int cy_bn_scratch_rows(void);
 
 /* Weight gradient: part[sp][CoRows][ks*ks*Ci] = sum over the pixels of split sp of dy[p][co] * x[p (+) tap][ci].
  * dy: view (N,OH,OW,Co,lddy) ; x: view (N,XH,XW,Ci,ldx).  `split` partial slabs are written (not accumulated);

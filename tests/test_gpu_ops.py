@@ -66,11 +66,11 @@ def test_conv_forward_and_stats(dt, case):
     OH, OW = ref.shape[2], ref.shape[3]
     out = View.alloc(N, OH, OW, Co, dt, ld=Co + 32, zero=True)
     rows = ops.conv_stats_rows(N * OH * OW, Co)
-    stats = torch.zeros(rows, 2, Co, device=DEV)
+    stats = torch.zeros(rows + ops.bn_scratch_rows(), 2, Co, device=DEV)
     ops.conv_igemm(xv, wf, Co, out, ks, st, pad, flags=ops.CONV_STATS, stats=stats)
     got = out.to_nchw().cpu()
     torch.testing.assert_close(got, ref, **_tol(dt))
-    s = stats.sum(0).cpu()
+    s = stats[:rows].sum(0).cpu()
     torch.testing.assert_close(s[0], ref.double().sum((0, 2, 3)).float(), rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(s[1], (ref.double() ** 2).sum((0, 2, 3)).float(), rtol=1e-3, atol=1e-2)
 
@@ -166,6 +166,7 @@ def test_bn_act_forward_backward(dt, act, with_res):
     # device: statistics from partial sums (as the conv epilogue would emit them)
     xv = View.from_nchw(x.to(DEV), dt)
     stats = torch.stack((x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3)))).float().view(1, 2, C).to(DEV)
+    stats = torch.cat((stats, torch.zeros(ops.bn_scratch_rows(), 2, C, device=DEV)))
     dev = lambda t: t.clone().to(DEV)
     mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
     d_rm, d_rv = dev(rm), dev(rv)
@@ -182,7 +183,7 @@ def test_bn_act_forward_backward(dt, act, with_res):
     # backward
     dyv = View.from_nchw(dy.to(DEV), dt)
     rows = ops.bn_bwd_rows(M, C, dt)
-    part = torch.zeros(rows, 2, C, device=DEV)
+    part = torch.zeros(rows + ops.bn_scratch_rows(), 2, C, device=DEV)
     ops.bn_act_bwd_reduce(xv, dyv, mean, invstd, scale, shift, ops.ACT[act], part)
     dgs, dbs = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     gg, gb = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
