@@ -26,6 +26,11 @@ struct IgemmParams {
     int K, M, wrows;
     int flags;
     int mtiles, ntiles;
+    // pixel sub-lattice handled by this launch: oh = oh' * oh_mul + oh_off over OHc x OWc (the whole image for
+    // ordinary launches; one parity class for a stride-2 dgrad) and its taps, 2 bits per (kh, kw)
+    int OHc, OWc, oh_mul, oh_off, ow_mul, ow_off;
+    int ntaps;
+    unsigned kh_pack, kw_pack;
 };
 
 template <typename T>
@@ -81,13 +86,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     // ---- per-thread staging coordinates --------------------------------------------------------
     const int chunk = tid & 7, rbase = tid >> 3;
     int x_pix[XR], x_h[XR], x_w[XR];
-    const int ohw = p.OH * p.OW;
+    const int ohw = p.OHc * p.OWc;
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         const int m = tm * BM + rbase + 32 * i;
         if (m < p.M) {
             const int n = m / ohw, rem = m - n * ohw;
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int ohc = rem / p.OWc;
+            const int oh = ohc * p.oh_mul + p.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
             x_pix[i] = n * p.GH * p.GW;
             x_h[i] = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
             x_w[i] = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
@@ -99,13 +105,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     }
     int k_c = chunk * CH, k_tap = 0;  // this thread's chunk: channel offset and tap within the K tile
     while (k_c >= p.GC) { k_c -= p.GC; ++k_tap; }
-    const int ntaps = p.ks * p.ks;
+    const int ntaps = p.ntaps;
 
     u32x4 xv[XR], wv[WR];
     auto load_tile = [&](int kt) {
         const bool kvalid = k_tap < ntaps;
-        const int kh = (p.ks == 3) ? (k_tap * 11) >> 5 : 0;
-        const int kw = k_tap - kh * p.ks;
+        const int kh = (p.kh_pack >> (2 * k_tap)) & 3, kw = (p.kw_pack >> (2 * k_tap)) & 3;
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
             int gh, gw;
@@ -130,7 +135,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             }
             xv[i] = v;
         }
-        const int k = kt * BK + chunk * CH;
+        const int k = (kh * p.ks + kw) * p.GC + k_c;  // column of the packed weight matrix
+        (void)kt;
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
             const int co = tn * BN + rbase + 32 * i;
@@ -166,7 +172,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (p.K + BK - 1) / BK;
+    const int nkt = (p.ntaps * p.GC + BK - 1) / BK;
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -227,10 +233,17 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         }
     }
 
+    const bool sublattice = (p.oh_mul | p.ow_mul) != 1 || p.OHc != p.OH || p.OWc != p.OW;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-        const int m = mbase + j * 16;
-        if (m >= p.M) continue;
+        const int mj = mbase + j * 16;
+        if (mj >= p.M) continue;
+        int m = mj;
+        if (sublattice) {
+            const int n = mj / ohw, rem = mj - n * ohw;
+            const int ohc = rem / p.OWc;
+            m = (n * p.OH + ohc * p.oh_mul + p.oh_off) * p.OW + (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int co = cbase + i * 16;
@@ -348,5 +361,35 @@ extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int l
     p.mtiles = p.ntiles = 0;
     if (p.M <= 0 || OC <= 0) return CY_ERR_ARG;
     if (stats_rows_host) *stats_rows_host = cy_conv_stats_rows(p.M, OC);
-    return dtype == CY_F16 ? dispatch<f16>(p, cy_s(s)) : dispatch<float>(p, cy_s(s));
+    p.OHc = OH; p.OWc = OW; p.oh_mul = p.ow_mul = 1; p.oh_off = p.ow_off = 0;
+    p.ntaps = ks * ks; p.kh_pack = p.kw_pack = 0;
+    for (int t = 0; t < ks * ks; ++t) {
+        p.kh_pack |= (unsigned)(t / ks) << (2 * t);
+        p.kw_pack |= (unsigned)(t % ks) << (2 * t);
+    }
+    if (!(p.transposed && stride == 2))
+        return dtype == CY_F16 ? dispatch<f16>(p, cy_s(s)) : dispatch<float>(p, cy_s(s));
+    // stride-2 dgrad: an input-gradient pixel only sees the taps with (o + pad - k) even.  Four launches, one per
+    // (row, column) parity class, each over its own taps: 9 tap-visits in total instead of 36.
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            IgemmParams q = p;
+            q.OHc = (OH - ph + 1) / 2; q.OWc = (OW - pw + 1) / 2;
+            if (q.OHc <= 0 || q.OWc <= 0) continue;
+            q.oh_mul = q.ow_mul = 2; q.oh_off = ph; q.ow_off = pw;
+            q.M = N * q.OHc * q.OWc;
+            q.ntaps = 0; q.kh_pack = q.kw_pack = 0;
+            for (int kh = 0; kh < ks; ++kh) {
+                if ((ph + pad - kh) & 1) continue;
+                for (int kw = 0; kw < ks; ++kw) {
+                    if ((pw + pad - kw) & 1) continue;
+                    q.kh_pack |= (unsigned)kh << (2 * q.ntaps);
+                    q.kw_pack |= (unsigned)kw << (2 * q.ntaps);
+                    ++q.ntaps;
+                }
+            }
+            const int rc = dtype == CY_F16 ? dispatch<f16>(q, cy_s(s)) : dispatch<float>(q, cy_s(s));
+            if (rc) return rc;
+        }
+    return 0;
 }

@@ -50,6 +50,7 @@ CONV_CASES = [
     (1, 32, 64, 64, 64, 3, 2),
     (2, 256, 19, 19, 512, 1, 1),
     (3, 64, 21, 17, 32, 3, 1),
+    (2, 32, 21, 17, 64, 3, 2),
 ]
 
 
