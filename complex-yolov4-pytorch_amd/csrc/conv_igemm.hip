@@ -10,6 +10,8 @@
 // barrier per K step.  LDS rows are 128 B with the 16-byte chunk index XOR-swizzled by (row & 7):
 // conflict-free for the ds_read_b128 lane groups (see DESIGN.md section kernels).
 // f16: v_mfma_f32_16x16x32_f16.  f32 (parity mode): v_mfma_f32_16x16x4_f32, exact f32.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -31,6 +33,7 @@ struct IgemmParams {
     int OHc, OWc, oh_mul, oh_off, ow_mul, ow_off;
     int ntaps;
     unsigned kh_pack, kw_pack;
+    unsigned g_bytes, w_bytes;  // extents of the gathered view / weight matrix (buffer descriptors: OOB reads return 0)
 };
 
 template <typename T>
@@ -60,8 +63,9 @@ struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool GLDS, int NST = 2>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
+    static_assert(NST == 2 || GLDS, "the 3-stage ring needs direct-to-LDS loads");
     constexpr int CH = Elem<T>::CH;
     constexpr int BK = 8 * CH;
     constexpr int XR = BM / 32, WR = BN / 32;
@@ -84,74 +88,100 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     const int tn = lid % p.ntiles, tm = lid / p.ntiles;
 
     // ---- per-thread staging coordinates --------------------------------------------------------
-    const int chunk = tid & 7, rbase = tid >> 3;
-    int x_pix[XR], x_h[XR], x_w[XR];
+    // register staging: thread = (row tid>>3, chunk tid&7), swizzle applied on the LDS store.
+    // direct-to-LDS (GLDS): the LDS image of a wave-instruction is lane-linear (base + lane*16), so the swizzle moves to
+    // the SOURCE: lane l fills physical chunk l&7 of row l>>3, i.e. it fetches logical chunk (l&7)^(row&7).
+    const int chunk = GLDS ? ((lane & 7) ^ ((lane >> 3) & 7)) : (tid & 7);
+    const int rbase = GLDS ? (wave * 8 + (lane >> 3)) : (tid >> 3);
+    // Per row (pixel) of this thread: byte offset of the "tap (0,0)" source pixel and a bit mask of the taps that fall
+    // inside the image (and, for dgrad, on the stride lattice).  Per K step only  base + delta(tap) + channel  is left.
+    const int ksign = p.transposed ? -1 : 1;
+    const int sh = (p.transposed && p.stride == 2) ? 1 : 0;
+    unsigned x_base[XR], x_mask[XR];
     const int ohw = p.OHc * p.OWc;
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         const int m = tm * BM + rbase + 32 * i;
+        x_base[i] = 0u;
+        x_mask[i] = 0u;
         if (m < p.M) {
             const int n = m / ohw, rem = m - n * ohw;
             const int ohc = rem / p.OWc;
             const int oh = ohc * p.oh_mul + p.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
-            x_pix[i] = n * p.GH * p.GW;
-            x_h[i] = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
-            x_w[i] = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
-        } else {
-            x_pix[i] = 0;
-            x_h[i] = -(1 << 20);
-            x_w[i] = -(1 << 20);
+            const int xh = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
+            const int xw = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int kh = (p.kh_pack >> (2 * t)) & 3, kw = (p.kw_pack >> (2 * t)) & 3;
+                const int th = xh + ksign * kh, tw = xw + ksign * kw;
+                const bool ok = (((th | tw) & sh) == 0) & ((unsigned)(th >> sh) < (unsigned)p.GH) &
+                                ((unsigned)(tw >> sh) < (unsigned)p.GW);
+                x_mask[i] |= (ok ? 1u : 0u) << t;
+            }
+            // for valid dgrad taps (th even) (xh - kh) >> 1 == (xh >> 1) - (kh >> 1), so the offset stays linear in the tap
+            x_base[i] = (unsigned)(((n * p.GH + (xh >> sh)) * p.GW + (xw >> sh)) * p.ldg) * (unsigned)sizeof(T);
         }
     }
+    const unsigned w_row0 = (unsigned)(tn * BN + rbase) * (unsigned)p.K * (unsigned)sizeof(T);
+    const unsigned w_rstep = 32u * (unsigned)p.K * (unsigned)sizeof(T);
     int k_c = chunk * CH, k_tap = 0;  // this thread's chunk: channel offset and tap within the K tile
     while (k_c >= p.GC) { k_c -= p.GC; ++k_tap; }
     const int ntaps = p.ntaps;
+    const int adv_tap = BK / p.GC, adv_c = BK - adv_tap * p.GC;
+    // buffer descriptors: 32-bit byte offsets, and an out-of-range offset makes the DMA write zeros -- which is exactly
+    // the zero fill padding / the K tail / dgrad holes need (a direct-to-LDS load cannot write a literal)
+    const auto rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    (void)rs_g; (void)rs_w;
 
     u32x4 xv[XR], wv[WR];
-    auto load_tile = [&](int kt) {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto load_tile = [&](int kt, int stage) {
+        unsigned char* xs_w = smem + stage * STAGE + wave_u * (8 * 128);
+        unsigned char* ws_w = xs_w + BM * 128;
+        (void)xs_w; (void)ws_w;
         const bool kvalid = k_tap < ntaps;
-        const int kh = (p.kh_pack >> (2 * k_tap)) & 3, kw = (p.kw_pack >> (2 * k_tap)) & 3;
+        const int tsh = 2 * min(k_tap, 15);
+        const int kh = (p.kh_pack >> tsh) & 3, kw = (p.kw_pack >> tsh) & 3;
+        // source offset of this tap relative to tap (0,0), launch-uniform geometry, per-thread tap only when GC < BK
+        const unsigned tap_delta = (unsigned)(ksign * (((kh >> sh) * p.GW + (kw >> sh)) * p.ldg) + k_c) * (unsigned)sizeof(T);
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
-            int gh, gw;
-            bool ok = kvalid;
-            if (p.transposed) {
-                const int th = x_h[i] - kh, tw = x_w[i] - kw;
-                if (p.stride == 2) {
-                    ok = ok && !((th | tw) & 1);
-                    gh = th >> 1; gw = tw >> 1;
-                } else {
-                    gh = th; gw = tw;
-                }
-                ok = ok && th >= 0 && tw >= 0;
+            const bool ok = kvalid & ((x_mask[i] >> k_tap) & 1u);
+            if constexpr (GLDS) {
+                const unsigned off = ok ? x_base[i] + tap_delta : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(xs_w + i * (32 * 128)),
+                                                         16, off, 0, 0, 0);
             } else {
-                gh = x_h[i] + kh; gw = x_w[i] + kw;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (ok) v = *reinterpret_cast<const u32x4*>(p.g + (size_t)(x_base[i] + tap_delta));
+                xv[i] = v;
             }
-            ok = ok && gh >= 0 && gh < p.GH && gw >= 0 && gw < p.GW;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) {
-                const size_t off = ((size_t)(x_pix[i] + gh * p.GW + gw) * p.ldg + k_c) * sizeof(T);
-                v = *reinterpret_cast<const u32x4*>(p.g + off);
-            }
-            xv[i] = v;
         }
-        const int k = (kh * p.ks + kw) * p.GC + k_c;  // column of the packed weight matrix
+        const unsigned koff = (unsigned)((kh * p.ks + kw) * p.GC + k_c) * (unsigned)sizeof(T);  // column of the packed weights
         (void)kt;
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
-            const int co = tn * BN + rbase + 32 * i;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (kvalid && co < p.wrows) {
-                const size_t off = ((size_t)co * p.K + k) * sizeof(T);
-                v = *reinterpret_cast<const u32x4*>(p.w + off);
+            const bool ok = kvalid & (tn * BN + rbase + 32 * i < p.wrows);
+            if constexpr (GLDS) {
+                const unsigned off32 = ok ? w_row0 + i * w_rstep + koff : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(ws_w + i * (32 * 128)),
+                                                         16, off32, 0, 0, 0);
+            } else {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (ok) v = *reinterpret_cast<const u32x4*>(p.w + (size_t)(w_row0 + i * w_rstep + koff));
+                wv[i] = v;
             }
-            wv[i] = v;
         }
-        // advance this thread's chunk to the next K tile
-        k_c += BK;
-        while (k_c >= p.GC) { k_c -= p.GC; ++k_tap; }
+        // advance this thread's chunk to the next K tile (branch-free: BK = adv_tap * GC + adv_c)
+        k_tap += adv_tap;
+        k_c += adv_c;
+        const bool wrap = k_c >= p.GC;
+        k_c -= wrap ? p.GC : 0;
+        k_tap += wrap ? 1 : 0;
     };
     auto store_tile = [&](int stage) {
+        if constexpr (GLDS) return;
         unsigned char* xs = smem + stage * STAGE;
         unsigned char* ws = xs + BM * 128;
 #pragma unroll
@@ -173,13 +203,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = (p.ntaps * p.GC + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const unsigned char* xs = smem + cur * STAGE;
+    auto compute_tile = [&](int stage) {
+        const unsigned char* xs = smem + stage * STAGE;
         const unsigned char* ws = xs + BM * 128;
         const unsigned char* wrow = ws + (wn * (BN / 2) + (lane & 15)) * 128;
         const unsigned char* xrow = xs + (wm * (BM / 2) + (lane & 15)) * 128;
@@ -195,8 +220,31 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
         }
-        if (kt + 1 < nkt) store_tile(cur ^ 1);
+    };
+    if constexpr (NST == 2) {
+        load_tile(0, 0);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) load_tile(kt + 1, cur ^ 1);
+            compute_tile(cur);
+            if (kt + 1 < nkt) store_tile(cur ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // 3-stage ring of direct-to-LDS tiles: two tiles in flight across the barrier (counted vmcnt + raw s_barrier;
+        // __syncthreads() would drain the DMA queue).  Tile kt is consumed one barrier after the wait that retires it.
+        constexpr int LPT = XR + WR;  // DMA instructions per tile per wave
+        load_tile(0, 0);
+        if (nkt > 1) load_tile(1, 1);
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nkt) load_tile(kt + 2, (kt + 2) % 3);
+            compute_tile(kt % 3);
+        }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -207,7 +255,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     const bool accum = (p.flags & CY_CONV_ACCUM) != 0;
 
     if (p.flags & CY_CONV_STATS) {
-        float* srow = p.stats + (size_t)(tm * 2 + wm) * 2 * p.OC;
+        // 64 bins of (sum, sumsq) per channel, fp32 atomics: at most blocks/32 adds per address, no fold launch needed
+        float* srow = p.stats + (size_t)(lid & 63) * 2 * p.OC;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -226,8 +275,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                 }
                 const int co = cbase + i * 16 + r;
                 if ((lane & 15) == 0 && co < p.OC) {
-                    srow[co] = s;
-                    srow[p.OC + co] = q;
+                    atomicAdd(srow + co, s);
+                    atomicAdd(srow + p.OC + co, q);
                 }
             }
         }
@@ -293,21 +342,41 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     }
 }
 
-template <typename T, int BM, int BN>
-int launch(const IgemmParams& p0, hipStream_t s) {
+template <typename T, int BM, int BN, bool GLDS, int NST>
+int launch_v(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.OC + BN - 1) / BN;
-    const int smem = 2 * (BM + BN) * 128;
+    const int smem = NST * (BM + BN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GLDS, NST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, s, p);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, GLDS, NST>), dim3(p.mtiles * p.ntiles), dim3(256), smem, s, p);
     CY_LAUNCH_CHECK();
     return 0;
+}
+
+// CY_IGEMM_GLDS: 0 = register-staged double buffer, 1 = direct-to-LDS double buffer, 3 = direct-to-LDS 3-stage ring
+// (kept selectable for A/B measurements)
+inline int glds_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CY_IGEMM_GLDS");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+template <typename T, int BM, int BN>
+int launch(const IgemmParams& p, hipStream_t s) {
+    const int m = glds_mode();
+    const bool longk = p.ntaps * p.GC > 2 * 128 / (int)sizeof(T);
+    if (m == 3 && longk) return launch_v<T, BM, BN, true, 3>(p, s);
+    if (m == 4 && longk && BM + BN <= 192) return launch_v<T, BM, BN, true, 3>(p, s);  // ring only where 2+ blocks/CU still fit
+    return m ? launch_v<T, BM, BN, true, 2>(p, s) : launch_v<T, BM, BN, false, 2>(p, s);
 }
 
 // Tile choice: channels tile = min(128, OC rounded up to 32); pixel tile 128 unless that leaves
@@ -336,10 +405,8 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int cy_conv_stats_rows(int M, int OC) {
-    CY_ENTER();
-    int bm, bn;
-    pick_tile(M, OC, bm, bn);
-    return 2 * ((M + bm - 1) / bm);
+    (void)M; (void)OC;
+    return 64;
 }
 
 extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows,
@@ -361,6 +428,10 @@ extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int l
     p.mtiles = p.ntiles = 0;
     if (p.M <= 0 || OC <= 0) return CY_ERR_ARG;
     if (stats_rows_host) *stats_rows_host = cy_conv_stats_rows(p.M, OC);
+    const size_t esz = dtype == CY_F16 ? 2 : 4;
+    const size_t gb = (((size_t)N * GH * GW - 1) * ldg + GC) * esz, wb = (size_t)wrows * p.K * esz;
+    if (gb >= 0xFFFFFF00ull || wb >= 0xFFFFFF00ull) return CY_ERR_ARG;  // 32-bit buffer offsets
+    p.g_bytes = (unsigned)gb; p.w_bytes = (unsigned)wb;
     p.OHc = OH; p.OWc = OW; p.oh_mul = p.ow_mul = 1; p.oh_off = p.ow_off = 0;
     p.ntaps = ks * ks; p.kh_pack = p.kw_pack = 0;
     for (int t = 0; t < ks * ks; ++t) {

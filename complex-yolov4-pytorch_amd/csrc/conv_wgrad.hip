@@ -272,6 +272,40 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// table-driven fold: block -> (descriptor, first output element); 256 threads = 4 groups of 64 consecutive outputs,
+// each thread walks all slabs of its output (coalesced 256-byte reads per wave and slab)
+__global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const cy_reduce_desc* __restrict__ desc,
+                                                                const int* __restrict__ blocks, float scale,
+                                                                int accumulate) {
+    const cy_reduce_desc d = desc[blocks[2 * blockIdx.x]];
+    const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
+    const int kk = d.ks * d.ks;
+    const long total = (long)d.Co * kk * d.Ci;
+    const int ncols = kk * d.CiPad;
+    const size_t slab = (size_t)d.CoRows * ncols;
+#pragma unroll
+    for (int it = 0; it < CY_MULTI_ELEMS / 256; ++it) {
+        const long idx = first + it * 256 + threadIdx.x;
+        if (idx >= total) break;
+        const int ci = (int)(idx % d.Ci);
+        const long t = idx / d.Ci;
+        const int tap = (int)(t % kk), co = (int)(t / kk);
+        const float* src = d.part + (size_t)co * ncols + tap * d.CiPad + ci;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = 0;
+        for (; sp + 3 < d.split; sp += 4) {
+            s0 += src[(size_t)sp * slab];
+            s1 += src[(size_t)(sp + 1) * slab];
+            s2 += src[(size_t)(sp + 2) * slab];
+            s3 += src[(size_t)(sp + 3) * slab];
+        }
+        for (; sp < d.split; ++sp) s0 += src[(size_t)sp * slab];
+        const size_t dst = ((size_t)co * d.Ci + ci) * kk + tap;
+        const float v = scale * ((s0 + s1) + (s2 + s3));
+        d.grad[dst] = v + (accumulate ? d.grad[dst] : 0.f);
+    }
+}
+
 __global__ void probe_tr16_kernel(uint16_t* out) {
     __shared__ __attribute__((aligned(16))) uint16_t tile[16 * 16];
     const int lane = threadIdx.x;
@@ -324,6 +358,15 @@ extern "C" int cy_wgrad_reduce(const float* part, int split, int CoRows, int CiP
     const long total = (long)Co * Ci * ks * ks;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, cy_s(s), part, split, CoRows,
                        CiPad, ks, Co, Ci, scale, accumulate, grad);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_wgrad_reduce_multi(const cy_reduce_desc* desc, const int32_t* blocks, int nblocks, float scale,
+                                     int accumulate, cy_stream_t s) {
+    CY_ENTER();
+    if (!desc || !blocks || nblocks < 1) return CY_ERR_ARG;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, scale, accumulate);
     CY_LAUNCH_CHECK();
     return 0;
 }

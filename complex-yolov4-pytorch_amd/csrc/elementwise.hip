@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
         const int i = o % CH, which = (o / CH) & 1, ck = o / (2 * CH);
         float s = 0.f;
         for (int r = 0; r < rpp; ++r) s += red[((r * cpr + ck) * 2 + which) * CH + i];
-        part[((size_t)blockIdx.x * 2 + which) * C + ck * CH + i] = s;
+        atomicAdd(&part[((size_t)(blockIdx.x & 63) * 2 + which) * C + ck * CH + i], s);
     }
 }
 
@@ -137,43 +137,20 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-// Column sums of a [rows][2][C] float partial table, coalesced: lanes run over channels, the 4 waves of a block and
-// the blocks of grid.y run over rows.  Writes double chunk sums to chunk_out[chunk][2][C].
-constexpr int CY_COLSUM_CHUNKS = 64;
-__global__ void __launch_bounds__(256) colsum_chunk_kernel(const float* __restrict__ part, int rows, int C,
-                                                          double* __restrict__ chunk_out) {
-    __shared__ double red[4][2][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-    const int rpc = (rows + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = r0 + w; r < r1; r += 4) {
-            s += (double)part[((size_t)r * 2) * C + c];
-            q += (double)part[((size_t)r * 2 + 1) * C + c];
-        }
-    red[w][0][threadIdx.x & 63] = s;
-    red[w][1][threadIdx.x & 63] = q;
-    __syncthreads();
-    if (w == 0 && c < C) {
-        const int l = threadIdx.x;
-        chunk_out[((size_t)blockIdx.y * 2) * C + c] = red[0][0][l] + red[1][0][l] + red[2][0][l] + red[3][0][l];
-        chunk_out[((size_t)blockIdx.y * 2 + 1) * C + c] = red[0][1][l] + red[1][1][l] + red[2][1][l] + red[3][1][l];
-    }
-}
-
-// finish: one wave per channel, lane k loads chunk k (nchunk <= 64), butterfly sum
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ chunks, int nchunk, int C, double count,
+// finish: one wave per channel, lane k owns bin k of the [64][2][C] fp32 table (filled with atomics by the conv
+// epilogue / the backward reduce); the lane that read a bin zeroes it, so the table is clean for its next user.
+constexpr int CY_BINS = 64;
+__global__ void __launch_bounds__(256) bn_finalize_kernel(float* __restrict__ bins, int C, double count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* rmean, float* rvar, long long* nbt, float momentum,
                                                          float eps, float* mean, float* invstd, float* scale, float* shift) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    if (lane < nchunk) {
-        s = chunks[((size_t)lane * 2) * C + c];
-        q = chunks[((size_t)lane * 2 + 1) * C + c];
-    }
+    float* p0 = bins + ((size_t)lane * 2) * C + c;
+    float* p1 = bins + ((size_t)lane * 2 + 1) * C + c;
+    double s = (double)*p0, q = (double)*p1;
+    *p0 = 0.f;
+    *p1 = 0.f;
     s = wave_sum_d(s);
     q = wave_sum_d(q);
     if (lane != 0) return;
@@ -203,16 +180,15 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ chunks, int nchunk, int C,
-                                                             float* dgs, float* dbs, float* ggamma, float* gbeta,
-                                                             float gscale) {
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(float* __restrict__ bins, int C, float* dgs, float* dbs,
+                                                             float* ggamma, float* gbeta, float gscale) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    if (lane < nchunk) {
-        s1 = chunks[((size_t)lane * 2) * C + c];
-        s2 = chunks[((size_t)lane * 2 + 1) * C + c];
-    }
+    float* p0 = bins + ((size_t)lane * 2) * C + c;
+    float* p1 = bins + ((size_t)lane * 2 + 1) * C + c;
+    double s1 = (double)*p0, s2 = (double)*p1;
+    *p0 = 0.f;
+    *p1 = 0.f;
     s1 = wave_sum_d(s1);
     s2 = wave_sum_d(s2);
     if (lane != 0) return;
@@ -379,6 +355,37 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Co, int Ci,
     }
 }
 
+// Both packed layouts are written coalesced (the fp32 master is gathered instead: reads are absorbed by L2, scattered
+// 2-byte writes are not).  The block table enumerates elements of the forward layout; the dgrad layout has the same
+// element count, so the same block also writes "its" range of the dgrad matrix.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_weights_multi_kernel(const cy_pack_desc* __restrict__ desc,
+                                                                const int* __restrict__ blocks) {
+    const cy_pack_desc d = desc[blocks[2 * blockIdx.x]];
+    const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
+    const int kk = d.ks * d.ks;
+    const long total = (long)d.CoPad * kk * d.CiPad;
+    T* wf = (T*)d.wf;
+    T* wd = (T*)d.wd;
+#pragma unroll
+    for (int it = 0; it < CY_MULTI_ELEMS / 256; ++it) {
+        const long i = first + it * 256 + threadIdx.x;
+        if (i >= total) break;
+        {   // forward layout [co][tap][ci]
+            const int ci = (int)(i % d.CiPad);
+            const int tap = (int)((i / d.CiPad) % kk);
+            const int co = (int)(i / ((long)d.CiPad * kk));
+            wf[i] = (T)((co < d.Co && ci < d.Ci) ? d.w[((long)co * d.Ci + ci) * kk + tap] : 0.f);
+        }
+        if (wd) {   // dgrad layout [ci][tap][co]
+            const int co = (int)(i % d.CoPad);
+            const int tap = (int)((i / d.CoPad) % kk);
+            const int ci = (int)(i / ((long)d.CoPad * kk));
+            wd[i] = (T)((co < d.Co && ci < d.Ci) ? d.w[((long)co * d.Ci + ci) * kk + tap] : 0.f);
+        }
+    }
+}
+
 __global__ void bias_grad_kernel(const float* __restrict__ d, long M, int C, float scale,
                                  const float* __restrict__ scale_dev, float* gbias) {
     if (scale_dev) scale *= *scale_dev;
@@ -391,17 +398,6 @@ __global__ void bias_grad_kernel(const float* __restrict__ d, long M, int C, flo
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) gbias[c] += scale * (float)(red[0] + red[1] + red[2] + red[3]);
-}
-
-inline int colsum_chunks(int rows) {
-    const int n = (rows + 15) / 16;
-    return n < 1 ? 1 : (n > CY_COLSUM_CHUNKS ? CY_COLSUM_CHUNKS : n);
-}
-// chunk sums live behind the partial table, in the CY_BN_SCRATCH_ROWS extra rows the caller provides
-inline double* colsum_scratch(const float* part, int rows, int C) {
-    size_t off = (size_t)rows * 2 * C;
-    off = (off + 1) & ~(size_t)1;  // 8-byte alignment
-    return reinterpret_cast<double*>(const_cast<float*>(part) + off);
 }
 
 inline int grid_for(long total) {
@@ -451,14 +447,14 @@ extern "C" int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const voi
     return 0;
 }
 
-extern "C" int cy_bn_scratch_rows(void) { return 2 * CY_COLSUM_CHUNKS + 1; }
+extern "C" int cy_bn_scratch_rows(void) { return 0; }
 
 extern "C" int cy_bn_bwd_rows(int64_t M, int C, int dtype) {
     CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!rowmap_ok(C, ch)) return CY_ERR_ARG;
-    const int ppb = ppb_for(M, C, ch);
-    return (int)((M + ppb - 1) / ppb);
+    (void)M;
+    return CY_BINS;
 }
 
 extern "C" int cy_bn_act_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, int64_t M, int C,
@@ -516,10 +512,8 @@ extern "C" int cy_bn_finalize(const float* stats_part, int rows, int C, int64_t 
     CY_ENTER();
     if (!stats_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows < 1 || count < 1)
         return CY_ERR_ARG;
-    const int nchunk = colsum_chunks(rows);
-    double* chunks = colsum_scratch(stats_part, rows, C);
-    hipLaunchKernelGGL(colsum_chunk_kernel, dim3((C + 63) / 64, nchunk), dim3(256), 0, cy_s(s), stats_part, rows, C, chunks);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), (const double*)chunks, nchunk, C,
+    if (rows != CY_BINS) return CY_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), const_cast<float*>(stats_part), C,
                        (double)count, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum,
                        eps, mean, invstd, scale, shift);
     CY_LAUNCH_CHECK();
@@ -541,11 +535,9 @@ extern "C" int cy_bn_bwd_finalize(const float* part, int rows, int C, float* dga
                                   float* ggamma, float* gbeta, float gscale, cy_stream_t s) {
     CY_ENTER();
     if (!part || !dgamma_sum || !dbeta_sum || rows < 1) return CY_ERR_ARG;
-    const int nchunk = colsum_chunks(rows);
-    double* chunks = colsum_scratch(part, rows, C);
-    hipLaunchKernelGGL(colsum_chunk_kernel, dim3((C + 63) / 64, nchunk), dim3(256), 0, cy_s(s), part, rows, C, chunks);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), (const double*)chunks, nchunk,
-                       C, dgamma_sum, dbeta_sum, ggamma, gbeta, gscale);
+    if (rows != CY_BINS) return CY_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), const_cast<float*>(part), C,
+                       dgamma_sum, dbeta_sum, ggamma, gbeta, gscale);
     CY_LAUNCH_CHECK();
     return 0;
 }
@@ -680,6 +672,20 @@ extern "C" int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad
     hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), w, Co, Ci, ks, CoPad, CiPad, (T*)wf, (T*)wd);
     CY_DT_SWITCH(dtype, CY_PW(f16), CY_PW(float))
 #undef CY_PW
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* blocks, int nblocks, int dtype,
+                                     cy_stream_t s) {
+    CY_ENTER();
+    if (!desc || !blocks || nblocks < 1) return CY_ERR_ARG;
+    if (dtype == CY_F16)
+        hipLaunchKernelGGL((pack_weights_multi_kernel<f16>), dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks);
+    else if (dtype == CY_F32)
+        hipLaunchKernelGGL((pack_weights_multi_kernel<float>), dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks);
+    else
+        return CY_ERR_ARG;
     CY_LAUNCH_CHECK();
     return 0;
 }

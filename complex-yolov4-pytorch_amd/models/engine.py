@@ -42,8 +42,8 @@ class Engine:
         # per-conv persistent BN vectors and packed weights; shared scratch for the reductions
         self.bnvec, self.wf, self.wd = {}, {}, {}
         max_stats = max_bnrows = max_c = 1
-        max_wpart = 1
-        self.wsplit = {}
+        max_wpart = 0
+        self.wsplit, self.wslab_off = {}, {}
         for rec in plan.convs:
             C, M = rec['cout'], N * rec['H'] * rec['W']
             cop, cip = _pad32(C), rec['cin_pad']
@@ -59,11 +59,16 @@ class Engine:
             if training:
                 sp = ops.wgrad_split(M, cop, cip, rec['ks'])
                 self.wsplit[rec['idx']] = sp
-                max_wpart = max(max_wpart, sp * cop * kk * cip)
-        self.stats = torch.empty(max_stats, **f32)
-        self.bnpart = torch.empty(max_bnrows, **f32)
+                self.wslab_off[rec['idx']] = max_wpart
+                max_wpart += sp * cop * kk * cip
+        # binned-atomics tables: zero once, every finaliser leaves its table zeroed for the next layer
+        self.stats = torch.zeros(max_stats, **f32)
+        self.bnpart = torch.zeros(max_bnrows, **f32)
         self.dgs, self.dbs = torch.empty(max_c, **f32), torch.empty(max_c, **f32)
-        self.wpart = torch.empty(max_wpart if training else 1, **f32)
+        # split-K slabs of every conv stay resident until their group is folded (table-driven, a few launches per step)
+        self.wpart = torch.empty(max(max_wpart, 1), **f32)
+        self._pack_table = self._pack_key = None
+        self._reduce_groups = None
         self.dummy = torch.zeros(16, **f32)
         # pools
         self.argmax, self.pool_scratch = {}, None
@@ -101,9 +106,55 @@ class Engine:
         plan = self.plan
         ops.nchw_to_nhwc(x, plan.input.C, self.dt, out=self.view(plan.input))
         self.params = params
+        self._pack_all()
         for rec in plan.fwd:
             getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
         return self.outputs
+
+    def _pack_all(self):
+        """fp32 master weights -> packed f16/f32 matrices of every conv, one table-driven launch.  In eval mode the pack
+        is skipped while no parameter has changed (tensor version counters)."""
+        ws = [self.params['models.%d.conv%d.weight' % (r['idx'], r['n'])] for r in self.plan.convs]
+        key = tuple(w.data_ptr() for w in ws)
+        if self._pack_key != key:
+            items = [(w, self.wf[r['idx']], self.wd[r['idx']], _pad32(r['cout']), r['cin_pad']) for w, r in zip(ws, self.plan.convs)]
+            self._pack_table = ops.make_pack_table(items, self.device)
+            self._pack_key = key
+            self._pack_versions = None
+        if not self.training:
+            versions = tuple(w._version for w in ws)
+            if versions == self._pack_versions:
+                return
+            self._pack_versions = versions
+        ops.pack_weights_multi(self._pack_table[0], self._pack_table[1], self.dt)
+
+    def _build_reduce_groups(self):
+        """Partition the convs (backward order) into groups of >= 16M gradient elements; one fold launch per group."""
+        groups, cur, n = [], [], 0
+        for b in self.plan.bwd:
+            if b['op'] not in ('conv_bwd', 'head_conv_bwd'):
+                continue
+            rec = b['fwd']
+            cur.append(rec)
+            n += rec['cout'] * rec['cin'] * rec['ks'] * rec['ks']
+            if n >= (16 << 20):
+                groups.append(cur); cur, n = [], 0
+        if cur:
+            groups.append(cur)
+        self._reduce_groups = []
+        for g in groups:
+            items = []
+            for rec in g:
+                idx = rec['idx']
+                cop, cip, kk = _pad32(rec['cout']), rec['cin_pad'], rec['ks'] * rec['ks']
+                sp = self.wsplit[idx]
+                off = self.wslab_off[idx]
+                part = self.wpart[off:off + sp * cop * kk * cip]
+                items.append((part, self.grads['models.%d.conv%d.weight' % (idx, rec['n'])], sp, cop, cip, rec['ks'],
+                              rec['cout'], rec['cin']))
+            desc, blocks = ops.make_reduce_table(items, self.device)
+            self._reduce_groups.append(dict(last=g[-1]['idx'], mods=[r['idx'] for r in g], desc=desc, blocks=blocks))
+        self._reduce_key = self.grads[next(iter(self.grads))].data_ptr()
 
     def _conv_work(self, rec):
         """(algorithmic flops, algorithmic bytes) of one pass of this conv: 2*M*Cout*k*k*Cin with the REAL channel
@@ -123,9 +174,7 @@ class Engine:
         cname, bname = self._names(rec)
         P = self.params
         idx = rec['idx']
-        w = P[cname + '.weight']
         cop = _pad32(rec['cout'])
-        ops.pack_weights_into(w, cop, rec['cin_pad'], self.dt, self.wf[idx], self.wd[idx])
         xv = self.view(rec['x'])
         if not rec['bn']:
             ops.conv_igemm(xv, self.wf[idx], cop, self.view(rec['out']), rec['ks'], rec['stride'], rec['pad'],
@@ -186,20 +235,28 @@ class Engine:
         on_module_done(idx) is called after the kernels that finish module idx's parameter gradients are queued."""
         assert self.training
         self.grads, self.gout, self.ls = grads, gout_dev, float(loss_scale)
+        if self._reduce_groups is None or self._reduce_key != grads[next(iter(grads))].data_ptr():
+            self._build_reduce_groups()
+        flush_at = {g['last']: g for g in self._reduce_groups}
         for rec in self.plan.bwd:
             getattr(self, '_b_' + rec['op'])(rec)
-            if on_module_done is not None and rec['op'] in ('conv_bwd', 'head_conv_bwd'):
-                on_module_done(rec['fwd']['idx'])
+            if rec['op'] in ('conv_bwd', 'head_conv_bwd'):
+                g = flush_at.get(rec['fwd']['idx'])
+                if g is not None:
+                    ops.wgrad_reduce_multi(g['desc'], g['blocks'], 1.0 / self.ls, True)
+                    if on_module_done is not None:
+                        for idx in g['mods']:
+                            on_module_done(idx)
 
     def _wgrad(self, rec, dy, xv):
         idx = rec['idx']
         cname, _ = self._names(rec)
         cop, cip = _pad32(rec['cout']), rec['cin_pad']
         sp = self.wsplit[idx]
+        off = self.wslab_off[idx]
+        part = self.wpart[off:off + sp * cop * rec['ks'] * rec['ks'] * cip]
         with ops.prof('wgrad', *self._conv_work(rec)):
-            ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], self.wpart, sp)
-        ops.wgrad_reduce(self.wpart, sp, cop, cip, rec['ks'], rec['cout'], rec['cin'], 1.0 / self.ls, True,
-                         self.grads[cname + '.weight'])
+            ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, sp)
 
     def _dgrad(self, rec, dy, runs):
         wd = self.wd[rec['idx']]

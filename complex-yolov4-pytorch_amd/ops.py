@@ -166,6 +166,51 @@ def pack_weights_into(w, co_pad, ci_pad, dt, wf, wd):
     lib().call('cy_pack_weights', _p(w), Co, Ci, ks, co_pad, ci_pad, dt, _p(wf), _p(wd), _stream())
 
 
+MULTI_ELEMS = 1024
+
+
+def _block_table(counts):
+    """[(descriptor index, element count)] -> int32 [nblocks, 2] of (descriptor, first element / 256)."""
+    rows = []
+    for i, n in enumerate(counts):
+        for first in range(0, n, MULTI_ELEMS):
+            rows.append((i, first // 256))
+    return rows
+
+
+def make_pack_table(items, device):
+    """items: [(w fp32 [Co,Ci,k,k], wf, wd or None, CoPad, CiPad)] -> (desc bytes tensor, block table tensor, keepalive)."""
+    import struct
+    raw, counts = b'', []
+    for w, wf, wd, cop, cip in items:
+        Co, Ci, ks, _ = w.shape
+        raw += struct.pack('<QQQiiiiii', w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else 0, Co, Ci, ks, cop, cip, 0)
+        counts.append(cop * ks * ks * cip)
+    desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    blocks = torch.tensor(_block_table(counts), dtype=torch.int32, device=device)
+    return desc, blocks
+
+
+def pack_weights_multi(desc, blocks, dt):
+    lib().call('cy_pack_weights_multi', _p(desc), _p(blocks), blocks.shape[0], dt, _stream())
+
+
+def make_reduce_table(items, device):
+    """items: [(part tensor, grad tensor, split, CoRows, CiPad, ks, Co, Ci)]."""
+    import struct
+    raw, counts = b'', []
+    for part, grad, split, corows, cip, ks, Co, Ci in items:
+        raw += struct.pack('<QQiiiiii', part.data_ptr(), grad.data_ptr(), split, corows, cip, ks, Co, Ci)
+        counts.append(Co * ks * ks * Ci)
+    desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    blocks = torch.tensor(_block_table(counts), dtype=torch.int32, device=device)
+    return desc, blocks
+
+
+def wgrad_reduce_multi(desc, blocks, scale, accumulate):
+    lib().call('cy_wgrad_reduce_multi', _p(desc), _p(blocks), blocks.shape[0], float(scale), int(accumulate), _stream())
+
+
 def nchw_to_nhwc(x, cpad, dt, out=None):
     _require_gpu()
     N, C, H, W = x.shape

@@ -46,6 +46,22 @@ int cy_device_info(int* cus, int* wave);
 int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad, int CiPad, int dtype, void* wf, void* wd,
                     cy_stream_t s);
 
+/* Table-driven variants: ONE launch for every conv of the network (the per-layer calls above cost a kernel boundary
+ * each, ~110 per step).  `desc` is a device array of cy_pack_desc / cy_reduce_desc; `blocks` a device array of
+ * (descriptor index, first element / 256) pairs, one per 256-thread block covering CY_MULTI_ELEMS elements. */
+typedef struct {
+    const float* w; void* wf; void* wd;
+    int Co, Ci, ks, CoPad, CiPad, pad_;
+} cy_pack_desc;
+typedef struct {
+    const float* part; float* grad;
+    int split, CoRows, CiPad, ks, Co, Ci;
+} cy_reduce_desc;
+enum { CY_MULTI_ELEMS = 1024 };
+int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* blocks, int nblocks, int dtype, cy_stream_t s);
+int cy_wgrad_reduce_multi(const cy_reduce_desc* desc, const int32_t* blocks, int nblocks, float scale, int accumulate,
+                          cy_stream_t s);
+
 /* NCHW fp32 image batch [N][C][H][W] -> NHWC `dtype` view with CPad channels (extra channels zero).
  * (reference: the imgs tensor handed to Darknet.forward, darknet2pytorch.py:162) */
 int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dtype, void* out, cy_stream_t s);
@@ -54,18 +70,18 @@ int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dt
  *   forward : out[n,oh,ow,co] = sum_{kh,kw,ci} g[n, oh*stride-pad+kh, ow*stride-pad+kw, ci] * w[co][(kh,kw,ci)]
  *   dgrad   : (CY_CONV_TRANSPOSED) out = dX, g = dY, w = wd:  gh = (oh+pad-kh)/stride when divisible
  * g: view (N,GH,GW,GC,ldg);  out: view (N,OH,OW,OC,ldo);  w: [wrows][ks*ks*GC].
- * flags: CY_CONV_STATS       -> also write per-channel partial (sum, sumsq) of the f32 accumulators to
- *                               stats_part[prow][2][OC], prow = 2*mtile + half  (BatchNorm batch statistics)
+ * flags: CY_CONV_STATS       -> also ADD (fp32 atomics) per-channel partial (sum, sumsq) of the f32 accumulators into
+ *                               stats_part[bin][2][OC], bin = tile % 64  (BatchNorm batch statistics).  The table must
+ *                               be zero on entry; cy_bn_finalize folds it and leaves it zeroed.
  *        CY_CONV_BIAS_F32OUT -> out is float regardless of dtype and bias[OC] is added (the YOLO head convs)
  *        CY_CONV_ACCUM       -> out += result (gradient fan-in of routes / shortcuts)
  * Returns the number of stats rows written through *stats_rows when non-NULL. */
 int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out, int OH,
                   int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags, const float* bias,
                   float* stats_part, int* stats_rows_host, cy_stream_t s);
-/* Number of stats rows cy_conv_igemm writes for M = N*OH*OW output pixels. */
+/* Number of rows (bins) of the stats table cy_conv_igemm adds into (64). */
 int cy_conv_stats_rows(int M, int OC);
-/* Every [rows][2][C] partial table handed to cy_bn_finalize / cy_bn_bwd_finalize must have room for this many
- * EXTRA rows behind it: the finalisers fold the table in two coalesced stages and keep the stage-1 sums there. */
+/* Extra rows a partial table needs behind it (0 since the binned-atomics version; kept for ABI stability). */
 int cy_bn_scratch_rows(void);
 
 /* Weight gradient: part[sp][CoRows][ks*ks*Ci] = sum over the pixels of split sp of dy[p][co] * x[p (+) tap][ci].
@@ -93,8 +109,8 @@ int cy_bn_eval_affine(const float* gamma, const float* beta, const float* runnin
  * darknet2pytorch.py:208-219) in one pass.  x: (M pixels, C, ldx); y: ldy; res may be NULL. */
 int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
                   const float* scale, const float* shift, int act, int dtype, cy_stream_t s);
-/* Backward pass 1: per-channel partial sums of dz and dz*xhat, dz = dy*act'(x*scale+shift).
- * part[blocks][2][C]; returns rows via cy_bn_bwd_rows. */
+/* Backward pass 1: per-channel partial sums of dz and dz*xhat, dz = dy*act'(x*scale+shift), ADDED (fp32 atomics) into
+ * part[bin][2][C], cy_bn_bwd_rows() bins; zero on entry, cy_bn_bwd_finalize folds it and leaves it zeroed. */
 int cy_bn_act_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, int64_t M, int C, const float* mean,
                          const float* invstd, const float* scale, const float* shift, int act, int dtype,
                          float* part, cy_stream_t s);

