@@ -88,29 +88,39 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // ---- activations -------------------------------------------------------------------------------
 // Mish(x) = x*tanh(softplus(x)), softplus threshold 20 as torch (reference darknet2pytorch.py:22-28).
 // With n = e^x: tanh(log(1+n)) = n(n+2) / (n(n+2)+2).
+// FAST (fp16 storage mode): v_exp_f32 / v_rcp_f32 forms, ~1e-6 relative -- far below the fp16 rounding of the stored
+// result, and what keeps these HBM-bound passes from becoming VALU-bound (libm expf + two IEEE divisions cost ~50
+// VALU instructions per element).  The f32 parity mode keeps the accurate forms.
+template <bool FAST>
+__device__ __forceinline__ float cy_exp(float x) { return FAST ? __expf(x) : expf(x); }
+template <bool FAST>
+__device__ __forceinline__ float cy_div(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+
+template <bool FAST>
 __device__ __forceinline__ float mish_f(float x) {
     if (x > 20.f) return x;
-    const float n = expf(x);
+    const float n = cy_exp<FAST>(x);
     const float w = n * (n + 2.f);
-    return x * (w / (w + 2.f));
+    return x * cy_div<FAST>(w, w + 2.f);
 }
+template <bool FAST>
 __device__ __forceinline__ float mish_grad(float x) {
     if (x > 20.f) return 1.f;
-    const float n = expf(x);
+    const float n = cy_exp<FAST>(x);
     const float w = n * (n + 2.f);
-    const float t = w / (w + 2.f);               // tanh(softplus(x))
-    const float sg = n / (1.f + n);              // sigmoid(x)
+    const float t = cy_div<FAST>(w, w + 2.f);    // tanh(softplus(x))
+    const float sg = cy_div<FAST>(n, 1.f + n);   // sigmoid(x)
     return t + x * (1.f - t * t) * sg;
 }
-template <int ACT>
+template <int ACT, bool FAST = false>
 __device__ __forceinline__ float act_f(float z) {
-    if (ACT == CY_ACT_MISH) return mish_f(z);
+    if (ACT == CY_ACT_MISH) return mish_f<FAST>(z);
     if (ACT == CY_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
     return z;
 }
-template <int ACT>
+template <int ACT, bool FAST = false>
 __device__ __forceinline__ float act_grad(float z) {
-    if (ACT == CY_ACT_MISH) return mish_grad(z);
+    if (ACT == CY_ACT_MISH) return mish_grad<FAST>(z);
     if (ACT == CY_ACT_LEAKY) return z > 0.f ? 1.f : 0.1f;
     return 1.f;
 }

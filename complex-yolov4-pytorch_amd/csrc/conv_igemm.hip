@@ -10,6 +10,7 @@
 // barrier per K step.  LDS rows are 128 B with the 16-byte chunk index XOR-swizzled by (row & 7):
 // conflict-free for the ds_read_b128 lane groups (see DESIGN.md section kernels).
 // f16: v_mfma_f32_16x16x32_f16.  f32 (parity mode): v_mfma_f32_16x16x4_f32, exact f32.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -392,6 +393,15 @@ template <typename T>
 int dispatch(const IgemmParams& p, hipStream_t s) {
     int bm, bn;
     pick_tile(p.M, p.OC, bm, bn);
+    {   // CY_IGEMM_TILE=BMxBN forces a tile (tuning experiments)
+        static int fbm = -1, fbn = -1;
+        if (fbm < 0) {
+            const char* e = getenv("CY_IGEMM_TILE");
+            fbm = fbn = 0;
+            if (e) sscanf(e, "%dx%d", &fbm, &fbn);
+        }
+        if (fbm > 0) { bm = fbm; bn = fbn; }
+    }
     if (bm == 128) {
         if (bn == 128) return launch<T, 128, 128>(p, s);
         if (bn == 64) return launch<T, 128, 64>(p, s);

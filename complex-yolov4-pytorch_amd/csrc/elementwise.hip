@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const T* __restrict__ x
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            f[i] = act_f<ACT>(f[i] * sc[i] + sh[i]);
+            f[i] = act_f<ACT, sizeof(T) == 2>(f[i] * sc[i] + sh[i]);
             if (RES) f[i] += r[i];
         }
         *reinterpret_cast<u32x4*>(y + p * ldy + chunk * CH) = f32_to_chunk<T>(f);
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
         chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(dy + p * lddy + chunk * CH), g);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const float dz = g[i] * act_grad<ACT>(f[i] * sc[i] + sh[i]);
+            const float dz = g[i] * act_grad<ACT, sizeof(T) == 2>(f[i] * sc[i] + sh[i]);
             s1[i] += dz;
             s2[i] += dz * (f[i] - mu[i]) * is[i];
         }
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
         float o[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const float dz = g[i] * act_grad<ACT>(f[i] * sc[i] + sh[i]);
+            const float dz = g[i] * act_grad<ACT, sizeof(T) == 2>(f[i] * sc[i] + sh[i]);
             const float xh = (f[i] - mu[i]) * is[i];
             o[i] = sc[i] * (dz - mb[i] - xh * mg[i]);
         }
