@@ -109,7 +109,7 @@ def main():
     model = Darknet(CFG, use_giou_loss=True, dtype=a.dtype).to(dev)
     model.train()
     net = RcclDataParallel(model) if world > 1 else model
-    opt = create_optimizer(_OptCfg, model)
+    opt = create_optimizer(_OptCfg, model)          # FusedAdam (cy_adam_multi) on the device
     x = syn.bev_images(a.batch, a.size, seed=rank).to(dev)
     tg = syn.targets(a.batch, 6, a.size, seed=rank).to(dev)
 

@@ -9,6 +9,8 @@
 //
 // Grid = (column tiles of ks*ks*Ci, channel tiles of Co, split): split-K over pixels; each block
 // writes its own slab part[sp] (deterministic; cy_wgrad_reduce folds the slabs).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -325,8 +327,15 @@ extern "C" int cy_conv_wgrad_split(int M, int Co, int Ci, int ks) {
     CY_ENTER();
     const int ncols = ks * ks * Ci;
     const long tiles = (long)((Co + tile_of(Co) - 1) / tile_of(Co)) * ((ncols + tile_of(ncols) - 1) / tile_of(ncols));
-    long split = (768 + tiles - 1) / tiles;
-    const long max_by_work = (M + 511) / 512;  // at least 8 K steps per block
+    static long target = -1, minpix = -1;
+    if (target < 0) {
+        const char* e = getenv("CY_WGRAD_BLOCKS");
+        target = e ? atol(e) : 768;
+        const char* f = getenv("CY_WGRAD_MINPIX");
+        minpix = f ? atol(f) : 512;
+    }
+    long split = (target + tiles - 1) / tiles;
+    const long max_by_work = (M + minpix - 1) / minpix;  // at least minpix/64 K steps per block
     if (split > max_by_work) split = max_by_work;
     const long slab = (long)Co * ncols * 4;
     while (split > 1 && split * slab > (256L << 20)) --split;

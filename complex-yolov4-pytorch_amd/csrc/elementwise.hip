@@ -386,6 +386,28 @@ __global__ void __launch_bounds__(256) pack_weights_multi_kernel(const cy_pack_d
     }
 }
 
+__global__ void __launch_bounds__(256) adam_multi_kernel(const cy_adam_desc* __restrict__ desc, const int* __restrict__ blocks,
+                                                        float beta1, float beta2, float eps, float bc1, float bc2,
+                                                        int zero_grad) {
+    const cy_adam_desc d = desc[blocks[2 * blockIdx.x]];
+    const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
+    const float step = d.lr / bc1, rs2 = rsqrtf(bc2);
+#pragma unroll
+    for (int it = 0; it < CY_MULTI_ELEMS / 256; ++it) {
+        const long i = first + it * 256 + threadIdx.x;
+        if (i >= d.n) break;
+        float g = d.g[i];
+        const float p = d.p[i];
+        if (d.weight_decay != 0.f) g += d.weight_decay * p;
+        const float m = beta1 * d.m[i] + (1.f - beta1) * g;
+        const float v = beta2 * d.v[i] + (1.f - beta2) * g * g;
+        d.m[i] = m;
+        d.v[i] = v;
+        d.p[i] = p - step * m / (sqrtf(v) * rs2 + eps);
+        if (zero_grad) d.g[i] = 0.f;
+    }
+}
+
 __global__ void bias_grad_kernel(const float* __restrict__ d, long M, int C, float scale,
                                  const float* __restrict__ scale_dev, float* gbias) {
     if (scale_dev) scale *= *scale_dev;
@@ -686,6 +708,16 @@ extern "C" int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* bl
         hipLaunchKernelGGL((pack_weights_multi_kernel<float>), dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks);
     else
         return CY_ERR_ARG;
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2,
+                             float eps, float bias_corr1, float bias_corr2, int zero_grad, cy_stream_t s) {
+    CY_ENTER();
+    if (!desc || !blocks || nblocks < 1 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return CY_ERR_ARG;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, beta1, beta2, eps, bias_corr1,
+                       bias_corr2, zero_grad);
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -18,7 +18,11 @@ def create_optimizer(configs, model):
     if configs.optimizer_type == 'sgd':
         opt = torch.optim.SGD(pg0, lr=configs.lr, momentum=configs.momentum, nesterov=True)
     elif configs.optimizer_type == 'adam':
-        opt = torch.optim.Adam(pg0, lr=configs.lr)
+        if getattr(configs, 'fused_optimizer', True) and pg0 and pg0[0].is_cuda:
+            from ..optim import FusedAdam
+            opt = FusedAdam(pg0, lr=configs.lr)
+        else:
+            opt = torch.optim.Adam(pg0, lr=configs.lr)
     else:
         assert False, "Unknown optimizer type"
     opt.add_param_group({'params': pg1, 'weight_decay': configs.weight_decay})

@@ -62,6 +62,18 @@ int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* blocks, int n
 int cy_wgrad_reduce_multi(const cy_reduce_desc* desc, const int32_t* blocks, int nblocks, float scale, int accumulate,
                           cy_stream_t s);
 
+/* Fused multi-tensor Adam (torch.optim.Adam semantics: L2 weight decay added to the gradient, bias-corrected moments,
+ * p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)); one launch for every parameter of the model.  Replaces the reference's
+ * torch.optim.Adam.step() (src/utils/train_utils.py:21-50 builds the three parameter groups).  zero_grad != 0 clears each
+ * gradient after it is consumed. */
+typedef struct {
+    float* p; float* g; float* m; float* v;
+    int64_t n;
+    float lr, weight_decay;
+} cy_adam_desc;
+int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2, float eps,
+                  float bias_corr1, float bias_corr2, int zero_grad, cy_stream_t s);
+
 /* NCHW fp32 image batch [N][C][H][W] -> NHWC `dtype` view with CPad channels (extra channels zero).
  * (reference: the imgs tensor handed to Darknet.forward, darknet2pytorch.py:162) */
 int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dtype, void* out, cy_stream_t s);

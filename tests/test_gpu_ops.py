@@ -297,3 +297,29 @@ def test_table_driven_pack_and_reduce_match_single_calls():
     ops.wgrad_reduce_multi(desc, blocks, 0.25, True)
     for it, ref in zip(ritems, refs):
         torch.testing.assert_close(it[1], ref, rtol=1e-6, atol=1e-6)
+
+
+def test_fused_adam_matches_torch_adam():
+    """cy_adam_multi vs torch.optim.Adam (same three parameter groups as the reference's create_optimizer), 5 steps."""
+    from complex_yolov4_pytorch_amd.optim import FusedAdam
+    shapes = [(64, 32, 3, 3), (64,), (64,), (30, 256, 1, 1), (30,), (1000,)]
+    ref_p = [_rand(*s, seed=70 + i).to(DEV).requires_grad_(True) for i, s in enumerate(shapes)]
+    my_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    ref = torch.optim.Adam(ref_p[:2], lr=1e-2)
+    ref.add_param_group({'params': ref_p[2:4], 'weight_decay': 5e-4})
+    ref.add_param_group({'params': ref_p[4:]})
+    mine = FusedAdam(my_p[:2], lr=1e-2)
+    mine.add_param_group({'params': my_p[2:4], 'weight_decay': 5e-4})
+    mine.add_param_group({'params': my_p[4:]})
+    for step in range(5):
+        for i, (a, b) in enumerate(zip(ref_p, my_p)):
+            g = _rand(*a.shape, seed=100 + 10 * step + i).to(DEV)
+            a.grad = g.clone()
+            b.grad = g.clone()
+        if step == 3:
+            for opt in (ref, mine):
+                opt.param_groups[0]['lr'] = 3e-3          # what a LambdaLR scheduler does
+        ref.step()
+        mine.step()
+    for a, b in zip(ref_p, my_p):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
