@@ -24,6 +24,7 @@ struct WgradParams {
     int ks, stride, pad;
     int M, Ncols, CoRows;
     int pps;  // pixels per split (multiple of BKP)
+    int ncol_tiles, nco_tiles;
 };
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -53,7 +54,17 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
-    const int col0 = blockIdx.x * BCI, co0 = blockIdx.y * BCO, sp = blockIdx.z;
+    // XCD-aware order (hardware places block b on XCD b % 8): all (column tile, channel tile) blocks of one pixel range
+    // become neighbours on ONE XCD, so its L2 serves the dY / X tiles they share (PMC: 3.5x the algorithmic HBM fetch
+    // without this).
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int ct = lid % p.ncol_tiles, rest = lid / p.ncol_tiles;
+    const int col0 = ct * BCI, co0 = (rest % p.nco_tiles) * BCO, sp = rest / p.nco_tiles;
     const int pix_begin = sp * p.pps;
     const int pix_end = min(p.M, pix_begin + p.pps);
 
@@ -225,8 +236,10 @@ int launch(const WgradParams& p, int split, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    dim3 grid((p.Ncols + BCI - 1) / BCI, (p.CoRows + BCO - 1) / BCO, split);
-    hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI, USE_TR>), grid, dim3(256), smem, s, p);
+    WgradParams q = p;
+    q.ncol_tiles = (p.Ncols + BCI - 1) / BCI;
+    q.nco_tiles = (p.CoRows + BCO - 1) / BCO;
+    hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI, USE_TR>), dim3(q.ncol_tiles * q.nco_tiles * split), dim3(256), smem, s, q);
     CY_LAUNCH_CHECK();
     return 0;
 }
