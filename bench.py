@@ -51,6 +51,23 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
+def pmc_traffic(kernel, a):
+    """HBM bytes per launch of the kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs of this same command; FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
+    cannot be read from inside the process, so this is the recorded figure for the default workload, or None."""
+    if (a.batch, a.size, a.dtype) != (16, 608, 'f16'):
+        return None
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)[kernel]
+        return dict(bytes_per_launch=round(d['fetch_bytes_per_launch_corrected'] + d['write_bytes_per_launch']),
+                    fetch=round(d['fetch_bytes_per_launch_corrected']), write=round(d['write_bytes_per_launch']),
+                    unit='bytes', source='profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)')
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(batch, size, seconds_budget=20.0):
     """Oracle train step (forward + GIoU loss + backward) on the host cores, bounded sample."""
     from complex_yolov4_pytorch_amd.models.darknet_utils import parse_cfg
@@ -150,9 +167,11 @@ def main():
             ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[a.dtype]
             roofline = dict(bound='mfma', kernel='igemm_kernel (implicit-GEMM conv: forward + dgrad launches, all tile variants)',
-                            achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                            achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+                            traffic=pmc_traffic('igemm', a),
                             launches_per_step=ig['launches'] // 2, avg_launch_us=round(1e3 * ig['ms'] / ig['launches'], 2),
                             hbm_gbs_algorithmic=round(ig['bytes'] / (ig['ms'] * 1e-3) / 1e9, 1),
+                            algorithmic_bytes_per_launch=round(ig['bytes'] / ig['launches']),
                             measured='HIP events around every launch of the kernel on its launch stream, 2 extra steps after the timed region')
             wg = summ.get('wgrad')
             if wg:
