@@ -360,8 +360,8 @@ int launch_v(const IgemmParams& p0, hipStream_t s) {
     return 0;
 }
 
-// CY_IGEMM_GLDS: 0 = register-staged double buffer, 1 = direct-to-LDS double buffer, 3 = direct-to-LDS 3-stage ring
-// (kept selectable for A/B measurements)
+// CY_IGEMM_GLDS=0 selects the register-staged double buffer (kept for A/B measurements on the 64/128-pixel tiles);
+// default is the direct-to-LDS double buffer.  A 3-stage DMA ring (NST = 3) measured slower at equal LDS footprint.
 inline int glds_mode() {
     static int v = -1;
     if (v < 0) {
@@ -373,26 +373,40 @@ inline int glds_mode() {
 
 template <typename T, int BM, int BN>
 int launch(const IgemmParams& p, hipStream_t s) {
-    const int m = glds_mode();
-    const bool longk = p.ntaps * p.GC > 2 * 128 / (int)sizeof(T);
-    if (m == 3 && longk) return launch_v<T, BM, BN, true, 3>(p, s);
-    if (m == 4 && longk && BM + BN <= 192) return launch_v<T, BM, BN, true, 3>(p, s);  // ring only where 2+ blocks/CU still fit
-    return m ? launch_v<T, BM, BN, true, 2>(p, s) : launch_v<T, BM, BN, false, 2>(p, s);
+    if constexpr (BM == 128 || BM == 64) {
+        if (glds_mode() == 0) return launch_v<T, BM, BN, false, 2>(p, s);
+    }
+    return launch_v<T, BM, BN, true, 2>(p, s);
 }
 
-// Tile choice: channels tile = min(128, OC rounded up to 32); pixel tile 128 unless that leaves
-// the 256 CUs under-filled.
-inline void pick_tile(int M, int OC, int& bm, int& bn) {
+// Tile choice.  Channel tile = min(128, OC rounded up to 32).  Pixel tile: blocks run in rounds of 256 * blocks-per-CU
+// (LDS-limited) and a K step costs ~1 us per resident block almost independently of the tile area (the double-buffered
+// loop is latency-bound; tools/tile_sweep*.sh), so
+//   * a problem that does not even fill one round of 128-pixel tiles uses 64-pixel tiles (more blocks in flight);
+//   * a problem that needs several rounds uses 192-pixel tiles when that saves a round (e.g. the 76x76 layers at
+//     batch 16: 722 tiles = 2 rounds at 128, 482 tiles = 1 round at 192; measured in-model 0.43 -> 0.375 ms).
+inline long tile_rounds(int M, int OC, int bm, int bn) {
+    int per_cu = (160 * 1024) / (2 * (bm + bn) * 128);
+    if (per_cu > 8) per_cu = 8;
+    const long tiles = (long)((M + bm - 1) / bm) * ((OC + bn - 1) / bn);
+    return (tiles + 256L * per_cu - 1) / (256L * per_cu);
+}
+inline void pick_tile(int M, int OC, int K, int esize, int& bm, int& bn) {
+    (void)K; (void)esize;
     bn = OC > 64 ? 128 : (OC > 32 ? 64 : 32);
     bm = 128;
     const long blocks128 = (long)((M + 127) / 128) * ((OC + bn - 1) / bn);
-    if (blocks128 < 512) bm = 64;
+    if (blocks128 < 512) {
+        bm = 64;
+    } else if (bn >= 64 && tile_rounds(M, OC, 192, bn) < tile_rounds(M, OC, 128, bn)) {
+        bm = 192;
+    }
 }
 
 template <typename T>
 int dispatch(const IgemmParams& p, hipStream_t s) {
     int bm, bn;
-    pick_tile(p.M, p.OC, bm, bn);
+    pick_tile(p.M, p.OC, p.ntaps * p.GC, (int)sizeof(T), bm, bn);
     {   // CY_IGEMM_TILE=BMxBN forces a tile (tuning experiments)
         static int fbm = -1, fbn = -1;
         if (fbm < 0) {
@@ -402,14 +416,13 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
         }
         if (fbm > 0) { bm = fbm; bn = fbn; }
     }
-    if (bm == 128) {
-        if (bn == 128) return launch<T, 128, 128>(p, s);
-        if (bn == 64) return launch<T, 128, 64>(p, s);
-        return launch<T, 128, 32>(p, s);
-    }
-    if (bn == 128) return launch<T, 64, 128>(p, s);
-    if (bn == 64) return launch<T, 64, 64>(p, s);
-    return launch<T, 64, 32>(p, s);
+#define CY_TILE(BM_, BN_) \
+    if (bm == BM_ && bn == BN_) return launch<T, BM_, BN_>(p, s);
+    CY_TILE(128, 128) CY_TILE(128, 64) CY_TILE(128, 32) CY_TILE(64, 128) CY_TILE(64, 64) CY_TILE(64, 32)
+    CY_TILE(192, 128) CY_TILE(192, 64) CY_TILE(160, 128) CY_TILE(160, 64) CY_TILE(96, 128) CY_TILE(96, 64) CY_TILE(256, 64)
+    CY_TILE(256, 128)
+#undef CY_TILE
+    return CY_ERR_ARG;
 }
 
 }  // namespace
