@@ -69,6 +69,9 @@ class Engine:
         self.wpart = torch.empty(max(max_wpart, 1), **f32)
         self._pack_table = self._pack_key = None
         self._reduce_groups = None
+        import os
+        use_side = training and getattr(device, 'type', str(device)) == 'cuda' and os.environ.get('CY_WGRAD_SIDE_STREAM', '1') != '0'
+        self.side = torch.cuda.Stream(device=device) if use_side else None
         self.dummy = torch.zeros(16, **f32)
         # pools
         self.argmax, self.pool_scratch = {}, None
@@ -243,12 +246,41 @@ class Engine:
             if rec['op'] in ('conv_bwd', 'head_conv_bwd'):
                 g = flush_at.get(rec['fwd']['idx'])
                 if g is not None:
-                    ops.wgrad_reduce_multi(g['desc'], g['blocks'], 1.0 / self.ls, True)
-                    if on_module_done is not None:
-                        for idx in g['mods']:
-                            on_module_done(idx)
+                    self._flush_group(g, on_module_done)
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+    def _flush_group(self, g, on_module_done):
+        """Fold the split-K slabs of one group of convs into the flat gradient and announce its modules as final.  With
+        the side stream this also runs there (after the main stream's BN-parameter gradients of the group, which the
+        side stream waits for), so the main stream never stalls on weight gradients before the end of backward."""
+        if self.side is None:
+            ops.wgrad_reduce_multi(g['desc'], g['blocks'], 1.0 / self.ls, True)
+            if on_module_done is not None:
+                for idx in g['mods']:
+                    on_module_done(idx)
+            return
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            ops.wgrad_reduce_multi(g['desc'], g['blocks'], 1.0 / self.ls, True)
+            if on_module_done is not None:
+                for idx in g['mods']:
+                    on_module_done(idx)
 
     def _wgrad(self, rec, dy, xv):
+        """Weight gradient of one conv.  It is off the critical path of backward (only the optimizer needs it), so it
+        is issued on a side HIP stream: its MFMA blocks fill the tails of, and run beside, the HBM-bound BN passes and
+        the dgrad of the following layers on the main stream.  The fold of each group waits for the side stream."""
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                self._wgrad_launch(rec, dy, xv)
+            return
+        self._wgrad_launch(rec, dy, xv)
+
+    def _wgrad_launch(self, rec, dy, xv):
         idx = rec['idx']
         cname, _ = self._names(rec)
         cop, cip = _pad32(rec['cout']), rec['cin_pad']
