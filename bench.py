@@ -118,14 +118,18 @@ def main():
         sys.exit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    force_ddp = os.environ.get('CY_DDP_FORCE') == '1'
+    if world > 1 or force_ddp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
 
     torch.manual_seed(0)
     model = Darknet(CFG, use_giou_loss=True, dtype=a.dtype).to(dev)
     model.train()
-    net = RcclDataParallel(model) if world > 1 else model
+    net = RcclDataParallel(model) if (world > 1 or force_ddp) else model
     opt = create_optimizer(_OptCfg, model)          # FusedAdam (cy_adam_multi) on the device
     x = syn.bev_images(a.batch, a.size, seed=rank).to(dev)
     tg = syn.targets(a.batch, 6, a.size, seed=rank).to(dev)
@@ -198,7 +202,7 @@ def main():
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -69,7 +69,7 @@ class _StepFn(torch.autograd.Function):
         if not eng.training:
             raise ops.CyoloError('backward needs model.train(): eval-mode engines keep no activations')
         grads = model._grad_table()
-        eng.backward(grads, gloss.detach().reshape(-1).float().contiguous(), model.loss_scale,
+        eng.backward(grads, gloss.detach().reshape(-1).float().contiguous(), model.loss_scale / model.grad_prescale, act_scale=model.loss_scale,
                      on_module_done=(lambda idx: [h(model, idx) for h in model._module_grad_hooks]) if model._module_grad_hooks else None)
         for hook in model._post_backward_hooks:
             hook(model)
@@ -99,6 +99,7 @@ class Darknet(nn.Module):
         self._grad_flat = None
         self._post_backward_hooks = []
         self._module_grad_hooks = []     # called as hook(model, module_idx) when a module's gradients are final
+        self.grad_prescale = 1.0         # folded into every parameter-gradient reduction (1/world under data parallelism)
 
     # ---- construction (reference create_network :235-401) -----------------------------------------
     def create_network(self, blocks):

@@ -233,11 +233,14 @@ class Engine:
                       rec['ignore_thresh'], use_giou, self.loss_ws[h], self.metrics[h], dl)
 
     # ---- backward --------------------------------------------------------------------------------
-    def backward(self, grads, gout_dev, loss_scale, on_module_done=None):
+    def backward(self, grads, gout_dev, loss_scale, on_module_done=None, act_scale=None):
         """grads: {param name: fp32 gradient tensor (accumulated into)}; gout_dev: device scalar d(loss).
+        ``act_scale`` multiplies d(logits) before the half-precision backward; parameter gradients are divided by
+        ``loss_scale`` (= act_scale, or act_scale * world so that a plain SUM all-reduce yields the mean).
         on_module_done(idx) is called after the kernels that finish module idx's parameter gradients are queued."""
         assert self.training
         self.grads, self.gout, self.ls = grads, gout_dev, float(loss_scale)
+        self.act_scale = float(loss_scale if act_scale is None else act_scale)
         if self._reduce_groups is None or self._reduce_key != grads[next(iter(grads))].data_ptr():
             self._build_reduce_groups()
         flush_at = {g['last']: g for g in self._reduce_groups}
@@ -331,8 +334,8 @@ class Engine:
         hd = self.plan.heads[h]
         M, nch = self.N * hd['G'] * hd['G'], hd['A'] * (7 + hd['C'])
         tmp = self.head_tmp[h]
-        ops.f32_to_view(self.dlogits[h], M, nch, self.ls, tmp, 32, scale_dev=self.gout)
-        ops.bias_grad(self.dlogits[h], M, nch, 1.0, self.grads[cname + '.bias'], scale_dev=self.gout)
+        ops.f32_to_view(self.dlogits[h], M, nch, self.act_scale, tmp, 32, scale_dev=self.gout)
+        ops.bias_grad(self.dlogits[h], M, nch, self.act_scale / self.ls, self.grads[cname + '.bias'], scale_dev=self.gout)
         self._wgrad(rec, tmp, self.view(rec['x']))
         self._dgrad(rec, tmp, b['dx'])
 

@@ -11,6 +11,7 @@ src/train.py:67,212) and its per-iteration loss all-reduce (src/utils/train_util
     ~50 ms step, so a few large buckets (default 64 MB) beat DDP's 25 MB default -- fewer, larger collectives;
   * no per-forward broadcast of BatchNorm buffers (DDP's broadcast_buffers default): BN statistics are per-GPU in
     the reference too (no SyncBN) and rank 0's are the ones checkpointed (train_utils.py:82-85);
+  * the 1/world of the mean is folded into the backward kernels' gradient reductions (no extra pass over 256 MB);
   * the loss scalar is reduced only when asked (``reduce_tensor``), not as a side effect.
 """
 import torch
@@ -24,14 +25,18 @@ class RcclDataParallel(torch.nn.Module):
         self.group = process_group
         self.bucket_bytes = int(bucket_bytes)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # CY_DDP_FORCE=1 runs the collectives even for a single rank (plumbing check on a 1-GPU box)
+        import os
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('CY_DDP_FORCE') == '1')
         self._side = None
         self._offsets = None
         self._tail = None
         self._pending = []
         module._post_backward_hooks.append(self._finish)
         module._module_grad_hooks.append(self._module_done)
-        if self.world > 1:
+        if self.active:
             self._broadcast_state()
+            module.grad_prescale = 1.0 / self.world   # the backward kernels emit gradient/world: SUM all-reduce = mean
 
     def _broadcast_state(self):
         """Rank 0's parameters and buffers everywhere (what the DDP constructor does once)."""
@@ -54,7 +59,7 @@ class RcclDataParallel(torch.nn.Module):
 
     def _reduce_range(self, lo, hi):
         flat = self.module.flat_grad
-        if flat is None or hi <= lo or self.world == 1:
+        if flat is None or hi <= lo or not self.active:
             return
         chunk = flat[lo:hi]
         if flat.is_cuda:
@@ -65,14 +70,12 @@ class RcclDataParallel(torch.nn.Module):
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
-                chunk.mul_(1.0 / self.world)
         else:
             dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
-            chunk.mul_(1.0 / self.world)
 
     def _module_done(self, model, idx):
         """Called by the engine after the backward of module ``idx``: every gradient at or after its offset is final."""
-        if self.world == 1:
+        if not self.active:
             return
         if self._offsets is None:
             self._prepare()
@@ -84,7 +87,7 @@ class RcclDataParallel(torch.nn.Module):
             self._tail = lo
 
     def _finish(self, model):
-        if self.world == 1:
+        if not self.active:
             return
         if self._offsets is None:
             self._prepare()
