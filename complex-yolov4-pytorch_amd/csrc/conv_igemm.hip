@@ -35,6 +35,11 @@ struct IgemmParams {
     int ntaps;
     unsigned kh_pack, kw_pack;
     unsigned g_bytes, w_bytes;  // extents of the gathered view / weight matrix (buffer descriptors: OOB reads return 0)
+    // CY_CONV_AFFINE_ACT epilogue (eval mode): out = act(acc * aff_scale[co] + aff_shift[co]) (+ res)
+    const float* aff_scale;
+    const float* aff_shift;
+    const unsigned char* res;
+    int act, ldres;
 };
 
 template <typename T>
@@ -299,6 +304,20 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             const int co = cbase + i * 16;
             if (co >= p.OC) continue;
             f32x4 v = acc[i][j];
+            if (p.flags & CY_CONV_AFFINE_ACT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = min(co + r, p.OC - 1);
+                    const float z = v[r] * p.aff_scale[c] + p.aff_shift[c];
+                    v[r] = p.act == CY_ACT_MISH ? mish_f<sizeof(T) == 2>(z) : (p.act == CY_ACT_LEAKY ? (z > 0.f ? z : 0.1f * z) : z);
+                }
+                if (p.res) {
+                    const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldres + co;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.OC) v[r] += (float)rp[r];
+                }
+            }
             if (f32out) {
                 float* dst = reinterpret_cast<float*>(p.o) + (size_t)m * p.ldo + co;
 #pragma unroll
@@ -432,10 +451,10 @@ extern "C" int cy_conv_stats_rows(int M, int OC) {
     return 64;
 }
 
-extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows,
-                             void* out, int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype,
-                             int flags, const float* bias, float* stats_part, int* stats_rows_host, cy_stream_t s) {
-    CY_ENTER();
+static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out,
+                           int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags,
+                           const float* bias, float* stats_part, int* stats_rows_host, const float* aff_scale,
+                           const float* aff_shift, int act, const void* res, int ldres, cy_stream_t s) {
     const int ch = dtype == CY_F16 ? 8 : 4;
     if (!g || !w || !out || (dtype != CY_F16 && dtype != CY_F32)) return CY_ERR_ARG;
     if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2) || GC % ch || ldg % ch) return CY_ERR_ARG;
@@ -444,6 +463,8 @@ extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int l
     IgemmParams p;
     p.g = (const unsigned char*)g; p.w = (const unsigned char*)w; p.o = (unsigned char*)out;
     p.bias = bias; p.stats = stats_part;
+    p.aff_scale = aff_scale; p.aff_shift = aff_shift; p.act = act; p.res = (const unsigned char*)res; p.ldres = ldres;
+    if ((flags & CY_CONV_AFFINE_ACT) && (!aff_scale || !aff_shift || (flags & (CY_CONV_STATS | CY_CONV_TRANSPOSED)))) return CY_ERR_ARG;
     p.N = N; p.GH = GH; p.GW = GW; p.GC = GC; p.ldg = ldg;
     p.OH = OH; p.OW = OW; p.OC = OC; p.ldo = ldo;
     p.ks = ks; p.stride = stride; p.pad = pad; p.transposed = (flags & CY_CONV_TRANSPOSED) ? 1 : 0;
@@ -486,4 +507,22 @@ extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int l
             if (rc) return rc;
         }
     return 0;
+}
+
+extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows,
+                             void* out, int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype,
+                             int flags, const float* bias, float* stats_part, int* stats_rows_host, cy_stream_t s) {
+    CY_ENTER();
+    if (flags & CY_CONV_AFFINE_ACT) return CY_ERR_ARG;
+    return conv_igemm_impl(g, N, GH, GW, GC, ldg, w, wrows, out, OH, OW, OC, ldo, ks, stride, pad, dtype, flags, bias,
+                           stats_part, stats_rows_host, nullptr, nullptr, 0, nullptr, 0, s);
+}
+
+extern "C" int cy_conv_bn_act_eval(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows,
+                                   void* out, int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype,
+                                   const float* scale, const float* shift, int act, const void* res, int ldres,
+                                   cy_stream_t s) {
+    CY_ENTER();
+    return conv_igemm_impl(g, N, GH, GW, GC, ldg, w, wrows, out, OH, OW, OC, ldo, ks, stride, pad, dtype,
+                           CY_CONV_AFFINE_ACT, nullptr, nullptr, nullptr, scale, shift, act, res, ldres, s);
 }

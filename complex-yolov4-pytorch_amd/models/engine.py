@@ -195,10 +195,15 @@ class Engine:
                             P[bname + '.running_mean'], P[bname + '.running_var'],
                             P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, mean, invstd, scale, shift)
         else:
-            with ops.prof('igemm', *self._conv_work(rec)):
-                ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'])
+            # eval: BN is an affine of the running statistics -> conv + BN + activation (+ shortcut) in one kernel,
+            # the pre-BN tensor is never materialised
             ops.bn_eval_affine(P[bname + '.weight'], P[bname + '.bias'], P[bname + '.running_mean'],
                                P[bname + '.running_var'], BN_EPS, scale, shift)
+            res = self.view(rec['res']) if rec['res'] is not None else None
+            with ops.prof('igemm', *self._conv_work(rec)):
+                ops.conv_bn_act_eval(xv, self.wf[idx], cop, self.view(rec['out']), rec['ks'], rec['stride'], rec['pad'],
+                                     scale, shift, ops.ACT[rec['act']], res)
+            return
         res = self.view(rec['res']) if rec['res'] is not None else None
         ops.bn_act_fwd(raw, self.view(rec['out']), res, scale, shift, ops.ACT[rec['act']])
 

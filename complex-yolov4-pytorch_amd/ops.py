@@ -252,6 +252,13 @@ def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None
                stride, pad, g.dt, flags, _p(bias), _p(stats), None, _stream())
 
 
+def conv_bn_act_eval(g, w, wrows, out, ks, stride, pad, scale, shift, act, res=None):
+    """Eval-mode conv + BN affine + activation (+ shortcut) in one kernel."""
+    _require_gpu()
+    lib().call('cy_conv_bn_act_eval', _p(g), g.N, g.H, g.W, g.C, g.ld, _p(w), wrows, _p(out), out.H, out.W, out.C, out.ld, ks,
+               stride, pad, g.dt, _p(scale), _p(shift), act, _p(res), res.ld if res is not None else 0, _stream())
+
+
 def wgrad_split(M, Co, Ci, ks):
     return lib().raw('cy_conv_wgrad_split')(M, Co, Ci, ks)
 

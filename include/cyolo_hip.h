@@ -28,7 +28,7 @@ enum { CY_F16 = 0, CY_F32 = 2 };
 enum { CY_ACT_LINEAR = 0, CY_ACT_LEAKY = 1, CY_ACT_MISH = 2 };
 enum { CY_ERR_ARG = -1 };
 /* cy_conv_igemm flags */
-enum { CY_CONV_STATS = 1, CY_CONV_BIAS_F32OUT = 2, CY_CONV_ACCUM = 4, CY_CONV_TRANSPOSED = 8 };
+enum { CY_CONV_STATS = 1, CY_CONV_BIAS_F32OUT = 2, CY_CONV_ACCUM = 4, CY_CONV_TRANSPOSED = 8, CY_CONV_AFFINE_ACT = 16 };
 
 int cy_version(void);
 /* Number of compute units / wavefront size of the current device (sanity for the loader). */
@@ -91,6 +91,13 @@ int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dt
 int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out, int OH,
                   int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags, const float* bias,
                   float* stats_part, int* stats_rows_host, cy_stream_t s);
+/* Eval-mode conv block in ONE kernel: out = act(conv(g, w) * scale[co] + shift[co]) (+ res), scale/shift being the
+ * BatchNorm affine of the running statistics (cy_bn_eval_affine).  The pre-BN tensor is never written
+ * (reference: the same nn.Sequential under model.eval(), evaluate.py:32-44). */
+int cy_conv_bn_act_eval(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out,
+                        int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, const float* scale,
+                        const float* shift, int act, const void* res, int ldres, cy_stream_t s);
+
 /* Number of rows (bins) of the stats table cy_conv_igemm adds into (64). */
 int cy_conv_stats_rows(int M, int OC);
 /* Extra rows a partial table needs behind it (0 since the binned-atomics version; kept for ABI stability). */

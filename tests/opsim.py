@@ -98,6 +98,16 @@ def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None
     _store(out, y, accumulate=bool(flags & CONV_ACCUM))
 
 
+def conv_bn_act_eval(g, w, wrows, out, ks, stride, pad, scale, shift, act, res=None):
+    x = _nchw(g)
+    wt = w.float().reshape(w.shape[0], ks * ks, g.C)[:out.C].permute(0, 2, 1).reshape(out.C, g.C, ks, ks)
+    y = F.conv2d(x, wt, None, stride, pad)
+    a = _act(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), act)
+    if res is not None:
+        a = a + _nchw(res)
+    _store(out, a)
+
+
 def conv_wgrad(dy, x, ks, stride, pad, part, split, use_tr=1):
     g, a = _nchw(dy), _nchw(x)
     dw = torch.nn.grad.conv2d_weight(a, (dy.C, x.C, ks, ks), g, stride, pad)     # [Co, Ci, kh, kw]
@@ -265,7 +275,7 @@ def yolo_loss(logits, B, G, A, C, targets, anchors, img_size, ignore_thresh, use
 
 
 NAMES = ['check_device_tensor', 'nchw_to_nhwc', 'pack_weights_into', 'make_pack_table', 'pack_weights_multi',
-         'make_reduce_table', 'wgrad_reduce_multi', 'conv_igemm', 'conv_wgrad', 'wgrad_reduce',
+         'make_reduce_table', 'wgrad_reduce_multi', 'conv_bn_act_eval', 'conv_igemm', 'conv_wgrad', 'wgrad_reduce',
          'bn_finalize', 'bn_eval_affine', 'bn_act_fwd', 'bn_act_bwd_reduce', 'bn_bwd_finalize', 'bn_act_bwd_apply',
          'maxpool_fwd', 'maxpool_bwd', 'upsample_fwd', 'upsample_bwd', 'slice_copy', 'slice_add', 'f32_to_view',
          'zero_view', 'bias_grad', 'yolo_decode', 'yolo_loss']

@@ -323,3 +323,23 @@ def test_fused_adam_matches_torch_adam():
         mine.step()
     for a, b in zip(ref_p, my_p):
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('dt', [CY_F16, CY_F32])
+@pytest.mark.parametrize('act', ['mish', 'leaky', 'linear'])
+def test_conv_bn_act_eval_fused(dt, act):
+    """Eval-mode conv block in one kernel vs conv -> affine -> activation (+ shortcut) in float64."""
+    N, Ci, H, W, Co, ks, st = 2, 64, 19, 19, 128, 3, 1
+    x = _round(_rand(N, Ci, H, W, seed=1), dt)
+    w = _round(_rand(Co, Ci, ks, ks, seed=2, scale=1 / math.sqrt(Ci * ks * ks)), dt)
+    res = _round(_rand(N, Co, H, W, seed=3), dt)
+    scale, shift = 1 + 0.2 * _rand(Co, seed=4), 0.3 * _rand(Co, seed=5)
+    z = F.conv2d(x.double(), w.double(), None, st, 1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    a = z * torch.tanh(F.softplus(z)) if act == 'mish' else (F.leaky_relu(z, 0.1) if act == 'leaky' else z)
+    ref = (a + res.double()).float()
+    xv, rv = View.from_nchw(x.to(DEV), dt), View.from_nchw(res.to(DEV), dt)
+    wf, _ = ops.pack_weights(w.to(DEV), Co, Ci, dt, want_dgrad=False)
+    out = View.alloc(N, H, W, Co, dt, ld=Co + 32, zero=True)
+    ops.conv_bn_act_eval(xv, wf, Co, out, ks, st, 1, scale.to(DEV), shift.to(DEV), ops.ACT[act], rv)
+    tol = dict(rtol=3e-3, atol=3e-3) if dt == CY_F16 else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.to_nchw().cpu(), ref, **tol)
