@@ -386,19 +386,23 @@ __global__ void __launch_bounds__(256) pack_weights_multi_kernel(const cy_pack_d
     }
 }
 
+struct AdamGroups {
+    float lr[8], wd[8];
+};
 __global__ void __launch_bounds__(256) adam_multi_kernel(const cy_adam_desc* __restrict__ desc, const int* __restrict__ blocks,
                                                         float beta1, float beta2, float eps, float bc1, float bc2,
-                                                        int zero_grad) {
+                                                        int zero_grad, AdamGroups grp) {
     const cy_adam_desc d = desc[blocks[2 * blockIdx.x]];
     const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
-    const float step = d.lr / bc1, rs2 = rsqrtf(bc2);
+    const float lr = grp.lr[d.group & 7], wdecay = grp.wd[d.group & 7];
+    const float step = lr / bc1, rs2 = rsqrtf(bc2);
 #pragma unroll
     for (int it = 0; it < CY_MULTI_ELEMS / 256; ++it) {
         const long i = first + it * 256 + threadIdx.x;
         if (i >= d.n) break;
         float g = d.g[i];
         const float p = d.p[i];
-        if (d.weight_decay != 0.f) g += d.weight_decay * p;
+        if (wdecay != 0.f) g += wdecay * p;
         const float m = beta1 * d.m[i] + (1.f - beta1) * g;
         const float v = beta2 * d.v[i] + (1.f - beta2) * g * g;
         d.m[i] = m;
@@ -713,11 +717,18 @@ extern "C" int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* bl
 }
 
 extern "C" int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2,
-                             float eps, float bias_corr1, float bias_corr2, int zero_grad, cy_stream_t s) {
+                             float eps, float bias_corr1, float bias_corr2, int zero_grad, const float* group_lr_host,
+                             const float* group_wd_host, int ngroups, cy_stream_t s) {
     CY_ENTER();
     if (!desc || !blocks || nblocks < 1 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return CY_ERR_ARG;
+    if (!group_lr_host || !group_wd_host || ngroups < 1 || ngroups > 8) return CY_ERR_ARG;
+    AdamGroups grp;
+    for (int i = 0; i < 8; ++i) {
+        grp.lr[i] = i < ngroups ? group_lr_host[i] : 0.f;
+        grp.wd[i] = i < ngroups ? group_wd_host[i] : 0.f;
+    }
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, beta1, beta2, eps, bias_corr1,
-                       bias_corr2, zero_grad);
+                       bias_corr2, zero_grad, grp);
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -212,20 +212,20 @@ def wgrad_reduce_multi(desc, blocks, scale, accumulate):
 
 
 def make_adam_table(items, device):
-    """items: [(p, g, m, v, lr, weight_decay)] fp32 contiguous device tensors of equal numel."""
+    """items: [(p, g, m, v, group index)] fp32 contiguous device tensors of equal numel."""
     import struct
     raw, counts = b'', []
-    for p_, g, m, v, lr, wd in items:
-        raw += struct.pack('<QQQQqff', p_.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p_.numel(), lr, wd)
+    for p_, g, m, v, grp in items:
+        raw += struct.pack('<QQQQqii', p_.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p_.numel(), grp, 0)
         counts.append(p_.numel())
     desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     blocks = torch.tensor(_block_table(counts), dtype=torch.int32, device=device)
     return desc, blocks
 
 
-def adam_multi(desc, blocks, beta1, beta2, eps, bc1, bc2, zero_grad=False):
+def adam_multi(desc, blocks, beta1, beta2, eps, bc1, bc2, lrs, wds, zero_grad=False):
     lib().call('cy_adam_multi', _p(desc), _p(blocks), blocks.shape[0], float(beta1), float(beta2), float(eps), float(bc1),
-               float(bc2), int(zero_grad), _stream())
+               float(bc2), int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _stream())
 
 
 def nchw_to_nhwc(x, cpad, dt, out=None):

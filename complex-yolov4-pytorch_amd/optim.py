@@ -17,7 +17,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _build(self):
         items = []
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -26,8 +26,8 @@ class FusedAdam(torch.optim.Optimizer):
                     st['exp_avg'] = torch.zeros_like(p.data)
                     st['exp_avg_sq'] = torch.zeros_like(p.data)
                     st['step'] = 0
-                items.append((p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], float(group['lr']), float(group['weight_decay'])))
-        key = tuple((i[0].data_ptr(), i[1].data_ptr(), i[4], i[5]) for i in items)
+                items.append((p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], gi))
+        key = tuple((i[0].data_ptr(), i[1].data_ptr(), i[4]) for i in items)
         if key != self._key:
             self._table = ops.make_adam_table(items, items[0][0].device) if items else None
             self._key = key
@@ -44,6 +44,8 @@ class FusedAdam(torch.optim.Optimizer):
             assert tuple(g['betas']) == (b1, b2) and g['eps'] == self.param_groups[0]['eps'], 'betas/eps must be shared'
         for st in self.state.values():
             st['step'] = self._steps
+        assert len(self.param_groups) <= 8
         ops.adam_multi(self._table[0], self._table[1], b1, b2, self.param_groups[0]['eps'], 1 - b1 ** self._steps,
-                       1 - b2 ** self._steps, zero_grad=zero_grad)
+                       1 - b2 ** self._steps, [g['lr'] for g in self.param_groups],
+                       [g['weight_decay'] for g in self.param_groups], zero_grad=zero_grad)
         return loss

@@ -69,10 +69,11 @@ int cy_wgrad_reduce_multi(const cy_reduce_desc* desc, const int32_t* blocks, int
 typedef struct {
     float* p; float* g; float* m; float* v;
     int64_t n;
-    float lr, weight_decay;
+    int group, pad_;      /* parameter group: learning rate / weight decay come per call (LR schedulers change them) */
 } cy_adam_desc;
 int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2, float eps,
-                  float bias_corr1, float bias_corr2, int zero_grad, cy_stream_t s);
+                  float bias_corr1, float bias_corr2, int zero_grad, const float* group_lr_host,
+                  const float* group_wd_host, int ngroups, cy_stream_t s);
 
 /* NCHW fp32 image batch [N][C][H][W] -> NHWC `dtype` view with CPad channels (extra channels zero).
  * (reference: the imgs tensor handed to Darknet.forward, darknet2pytorch.py:162) */
