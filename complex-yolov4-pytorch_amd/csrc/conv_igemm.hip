@@ -40,6 +40,7 @@ struct IgemmParams {
     const float* aff_shift;
     const unsigned char* res;
     int act, ldres;
+    int dbg_nomma;   // CY_IGEMM_NOMMA=1: skip the MFMA phase (load-path ceiling experiment)
 };
 
 template <typename T>
@@ -69,6 +70,18 @@ struct Mma<float> {
     }
 };
 
+// sum over the 16 lanes of a DPP row (every lane of the row ends up with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
 template <typename T, int BM, int BN, bool GLDS, int NST = 2>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     static_assert(NST == 2 || GLDS, "the 3-stage ring needs direct-to-LDS loads");
@@ -97,7 +110,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     // register staging: thread = (row tid>>3, chunk tid&7), swizzle applied on the LDS store.
     // direct-to-LDS (GLDS): the LDS image of a wave-instruction is lane-linear (base + lane*16), so the swizzle moves to
     // the SOURCE: lane l fills physical chunk l&7 of row l>>3, i.e. it fetches logical chunk (l&7)^(row&7).
-    const int chunk = GLDS ? ((lane & 7) ^ ((lane >> 3) & 7)) : (tid & 7);
+    const int chunk = GLDS ? ((lane & 7) ^ ((p.dbg_nomma & 2) ? 0 : ((lane >> 3) & 7))) : (tid & 7);   // dbg bit 1: no source swizzle (timing experiment only)
     const int rbase = GLDS ? (wave * 8 + (lane >> 3)) : (tid >> 3);
     // Per row (pixel) of this thread: byte offset of the "tap (0,0)" source pixel and a bit mask of the taps that fall
     // inside the image (and, for dgrad, on the stride lattice).  Per K step only  base + delta(tap) + channel  is left.
@@ -105,27 +118,39 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     const int sh = (p.transposed && p.stride == 2) ? 1 : 0;
     unsigned x_base[XR], x_mask[XR];
     const int ohw = p.OHc * p.OWc;
-#pragma unroll
-    for (int i = 0; i < XR; ++i) {
-        const int m = tm * BM + rbase + 32 * i;
-        x_base[i] = 0u;
-        x_mask[i] = 0u;
-        if (m < p.M) {
-            const int n = m / ohw, rem = m - n * ohw;
-            const int ohc = rem / p.OWc;
-            const int oh = ohc * p.oh_mul + p.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
-            const int xh = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
-            const int xw = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
-            for (int t = 0; t < p.ntaps; ++t) {
-                const int kh = (p.kh_pack >> (2 * t)) & 3, kw = (p.kw_pack >> (2 * t)) & 3;
-                const int th = xh + ksign * kh, tw = xw + ksign * kw;
-                const bool ok = (((th | tw) & sh) == 0) & ((unsigned)(th >> sh) < (unsigned)p.GH) &
-                                ((unsigned)(tw >> sh) < (unsigned)p.GW);
-                x_mask[i] |= (ok ? 1u : 0u) << t;
+    {
+        // one thread per pixel row works out (base, mask) once, the staging threads pick their XR rows up from LDS:
+        // the two integer divisions and the tap loop run once per row instead of once per (row, staging thread)
+        uint2* rowinfo = reinterpret_cast<uint2*>(smem);
+        if (tid < BM) {
+            const int m = tm * BM + tid;
+            unsigned base = 0u, mask = 0u;
+            if (m < p.M) {
+                const int n = m / ohw, rem = m - n * ohw;
+                const int ohc = rem / p.OWc;
+                const int oh = ohc * p.oh_mul + p.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
+                const int xh = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
+                const int xw = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
+                for (int t = 0; t < p.ntaps; ++t) {
+                    const int kh = (p.kh_pack >> (2 * t)) & 3, kw = (p.kw_pack >> (2 * t)) & 3;
+                    const int th = xh + ksign * kh, tw = xw + ksign * kw;
+                    const bool ok = (((th | tw) & sh) == 0) & ((unsigned)(th >> sh) < (unsigned)p.GH) &
+                                    ((unsigned)(tw >> sh) < (unsigned)p.GW);
+                    mask |= (ok ? 1u : 0u) << t;
+                }
+                // for valid dgrad taps (th even) (xh - kh) >> 1 == (xh >> 1) - (kh >> 1), so the offset stays linear in the tap
+                base = (unsigned)(((n * p.GH + (xh >> sh)) * p.GW + (xw >> sh)) * p.ldg) * (unsigned)sizeof(T);
             }
-            // for valid dgrad taps (th even) (xh - kh) >> 1 == (xh >> 1) - (kh >> 1), so the offset stays linear in the tap
-            x_base[i] = (unsigned)(((n * p.GH + (xh >> sh)) * p.GW + (xw >> sh)) * p.ldg) * (unsigned)sizeof(T);
+            rowinfo[tid] = make_uint2(base, mask);
         }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const uint2 ri = rowinfo[rbase + 32 * i];
+            x_base[i] = ri.x;
+            x_mask[i] = ri.y;
+        }
+        __syncthreads();   // stage 0 of the ring overlays rowinfo
     }
     const unsigned w_row0 = (unsigned)(tn * BN + rbase) * (unsigned)p.K * (unsigned)sizeof(T);
     const unsigned w_rstep = 32u * (unsigned)p.K * (unsigned)sizeof(T);
@@ -208,7 +233,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (p.ntaps * p.GC + BK - 1) / BK;
+    const int nkt = (p.dbg_nomma & 16) ? 1 : (p.ntaps * p.GC + BK - 1) / BK;   // dbg bit 4: one K step (fixed-cost experiment)
     auto compute_tile = [&](int stage) {
         const unsigned char* xs = smem + stage * STAGE;
         const unsigned char* ws = xs + BM * 128;
@@ -234,7 +259,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nkt) load_tile(kt + 1, cur ^ 1);
-            compute_tile(cur);
+            if (!(p.dbg_nomma & 1)) compute_tile(cur);
             if (kt + 1 < nkt) store_tile(cur ^ 1);
             __syncthreads();
         }
@@ -260,11 +285,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     const bool f32out = (p.flags & CY_CONV_BIAS_F32OUT) != 0;
     const bool accum = (p.flags & CY_CONV_ACCUM) != 0;
 
-    if (p.flags & CY_CONV_STATS) {
-        // 64 bins of (sum, sumsq) per channel, fp32 atomics: at most blocks/32 adds per address, no fold launch needed
-        float* srow = p.stats + (size_t)(lid & 63) * 2 * p.OC;
+    if ((p.flags & CY_CONV_STATS) && !(p.dbg_nomma & 8)) {
+        // per channel (sum, sumsq) of this block's BM pixels: 16-lane DPP row sums -> LDS [wm][2][BN] -> one coalesced
+        // fp32 atomic per (channel, moment) into one of 64 bins (at most blocks/64 adds per address, no fold launch)
+        if constexpr (NST != 2) __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
+            float sv = 0.f, qv = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = 0.f, q = 0.f;
@@ -274,17 +302,22 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
                     s += v;
                     q += v * v;
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s += __shfl_xor(s, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
-                const int co = cbase + i * 16 + r;
-                if ((lane & 15) == 0 && co < p.OC) {
-                    atomicAdd(srow + co, s);
-                    atomicAdd(srow + p.OC + co, q);
-                }
+                s = row16_sum(s);
+                q = row16_sum(q);
+                if ((lane & 3) == r) { sv = s; qv = q; }
             }
+            // lanes 0..3 of each 16-lane row publish r = lane & 3
+            if ((lane & 15) < 4) {
+                const int cl = wn * (BN / 2) + i * 16 + ((lane >> 4) << 2) + (lane & 3);
+                red[(wm * 2 + 0) * BN + cl] = sv;
+                red[(wm * 2 + 1) * BN + cl] = qv;
+            }
+        }
+        __syncthreads();
+        float* srow = p.stats + (size_t)(lid & 63) * 2 * p.OC;
+        for (int c = tid; c < 2 * BN; c += 256) {
+            const int mom = c / BN, cl = c - mom * BN, co = tn * BN + cl;
+            if (co < p.OC) atomicAdd(srow + mom * p.OC + co, red[mom * BN + cl] + red[(2 + mom) * BN + cl]);
         }
     }
 
@@ -292,7 +325,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int mj = mbase + j * 16;
-        if (mj >= p.M) continue;
+        if (mj >= p.M || (p.dbg_nomma & 4)) continue;
         int m = mj;
         if (sublattice) {
             const int n = mj / ohw, rem = mj - n * ohw;
@@ -367,7 +400,9 @@ int launch_v(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.OC + BN - 1) / BN;
-    const int smem = NST * (BM + BN) * 128;
+    static int lds_pad = -1;   // CY_IGEMM_LDS_PAD=bytes: occupancy experiments (forces fewer resident blocks per CU)
+    if (lds_pad < 0) { const char* e = getenv("CY_IGEMM_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
+    const int smem = NST * (BM + BN) * 128 + lds_pad;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GLDS, NST>),
@@ -463,6 +498,11 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
     IgemmParams p;
     p.g = (const unsigned char*)g; p.w = (const unsigned char*)w; p.o = (unsigned char*)out;
     p.bias = bias; p.stats = stats_part;
+    {
+        static int nomma = -1;
+        if (nomma < 0) { const char* e = getenv("CY_IGEMM_NOMMA"); nomma = e ? atoi(e) : 0; }
+        p.dbg_nomma = nomma;
+    }
     p.aff_scale = aff_scale; p.aff_shift = aff_shift; p.act = act; p.res = (const unsigned char*)res; p.ldres = ldres;
     if ((flags & CY_CONV_AFFINE_ACT) && (!aff_scale || !aff_shift || (flags & (CY_CONV_STATS | CY_CONV_TRANSPOSED)))) return CY_ERR_ARG;
     p.N = N; p.GH = GH; p.GW = GW; p.GC = GC; p.ldg = ldg;
