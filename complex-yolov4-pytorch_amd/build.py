@@ -8,8 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(HERE, '..', 'include')
 LIB = os.path.join(CSRC, 'libcyolo_hip.so')
-SOURCES = ['conv_igemm.hip', 'conv_wgrad.hip', 'elementwise.hip', 'yolo_head.hip', 'riou_nms.hip']
-HEADERS = ['common.hpp', 'geometry.hpp', os.path.join(INCLUDE, 'cyolo_hip.h')]
+SOURCES = ['conv_igemm.hip', 'conv_halo.hip', 'conv_wgrad.hip', 'elementwise.hip', 'yolo_head.hip', 'riou_nms.hip']
+HEADERS = ['common.hpp', 'igemm_common.hpp', 'geometry.hpp', os.path.join(INCLUDE, 'cyolo_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC, '-Wno-unused-value']
 
 
@@ -40,6 +40,9 @@ def build(force=False, verbose=False):
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
+        # dlopen it: a kernel stub the host pass dropped shows up as an undefined symbol only at load time
+        import ctypes
+        ctypes.CDLL(LIB)
     return LIB
 
 

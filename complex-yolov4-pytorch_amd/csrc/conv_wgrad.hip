@@ -24,6 +24,7 @@ struct WgradParams {
     int ks, stride, pad;
     int M, Ncols, CoRows;
     int pps;  // pixels per split (multiple of BKP)
+    unsigned x_bytes;  // extent of the X view (wgrad_dma_kernel's descriptor); 0 = offsets do not fit 32 bits
     int ncol_tiles, nco_tiles;
 };
 
@@ -226,6 +227,200 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// f16 weight gradient with direct-to-LDS tiles (the default f16 path; the register-staged kernel above stays for f32,
+// for the scalar-gather check of the transpose-read mapping and for offsets beyond 32 bits).
+//
+// PMC of the register-staged kernel at v4's shapes: 5.8 VALU instructions per MFMA (the per-row pixel bookkeeping and
+// 64-bit addresses of load_tile), a third of the LDS cycles lost to bank conflicts, MFMA pipe 17 % busy.  Here
+//   * tiles are [64 pixel rows][BC channels] with UNPADDED rows, filled by buffer_load ... lds in 1 KB pieces
+//     (1024 / row-bytes rows each); rows beyond the split, taps outside the image and channels beyond the matrix are
+//     out-of-range offsets = zero fill;
+//   * bank conflicts of ds_read_b64_tr_b16 are avoided by an XOR of the 32-byte column-pair index with a key of the
+//     row: a half-wave reads rows {r..r+3, r+8..r+11}, 32 bytes of one column pair each, and 256 bytes of distinct
+//     banks need, per row size,  256 B: key = (row&3) | ((row>>3)&1)<<2;  128 B: ((row>>1)&1) | ((row>>3)&1)<<1;
+//     64 B: (row>>3)&1.  For the rows a lane reads the key is a per-lane constant, so every LDS address of the MFMA
+//     phase is one per-lane constant plus an immediate;
+//   * the dY pieces advance linearly with the pixel (one add per piece and step); only the tap-shifted X rows keep
+//     the (n, oh, ow) bookkeeping, once per piece instead of once per 16-byte load.
+template <int RB>
+__device__ __forceinline__ int wg_key(int row) {
+    if constexpr (RB >= 256) return (row & 3) | (((row >> 3) & 1) << 2);
+    else if constexpr (RB == 128) return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    else return (row >> 3) & 1;
+}
+
+template <int BCO, int BCI>
+__global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) {
+    constexpr int BKP = 64;
+    constexpr int RBA = BCO * 2, RBB = BCI * 2;          // row bytes
+    constexpr int CPA = RBA / 16, CPB = RBB / 16;        // 16-byte chunks per row
+    constexpr int RPA = 64 / CPA, RPB = 64 / CPB;        // rows per 1 KB piece
+    constexpr int NPA = BKP / RPA / 4, NPB = BKP / RPB / 4;  // pieces per wave and K step
+    constexpr int STAGE = BKP * (RBA + RBB);
+    constexpr int TI = BCO / 32, TJ = BCI / 32;
+    static_assert(NPA >= 1 && NPB >= 1, "tile too narrow");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int ct = lid % p.ncol_tiles, rest = lid / p.ncol_tiles;
+    const int col0 = ct * BCI, co0 = (rest % p.nco_tiles) * BCO, sp = rest / p.nco_tiles;
+    const int pix_begin = sp * p.pps;
+    const int pix_end = min(p.M, pix_begin + p.pps);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // descriptors: dY is cut at the end of this block's pixel range (rows beyond it read as zero)
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)pix_end * (unsigned)p.lddy * 2u, 0x00020000);
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+    // ---- A pieces (dY): piece k of this wave = tile rows (wave + 4k) * RPA + lane / CPA ----------------------------
+    unsigned a_off[NPA];
+#pragma unroll
+    for (int k = 0; k < NPA; ++k) {
+        const int row = (wave + 4 * k) * RPA + lane / CPA;
+        const int lchunk = (lane % CPA) ^ (wg_key<RBA>(row) << 1);
+        const int co = co0 + lchunk * 8;
+        a_off[k] = co < p.Co ? ((unsigned)(pix_begin + row) * (unsigned)p.lddy + (unsigned)co) * 2u : 0xFFFFFFFFu;
+    }
+    const unsigned a_step = (unsigned)BKP * (unsigned)p.lddy * 2u;
+    // ---- B pieces (X shifted by the tap of the lane's column): pixel bookkeeping per piece -----------------------------
+    int bn[NPB], boh[NPB], bow[NPB], b_dh[NPB], b_dw[NPB];
+    unsigned b_ci[NPB];
+    bool b_cok[NPB];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+        const int row = (wave + 4 * k) * RPB + lane / CPB;
+        const int lchunk = (lane % CPB) ^ (wg_key<RBB>(row) << 1);
+        const int col = col0 + lchunk * 8;
+        b_cok[k] = col < p.Ncols;
+        const int tap = b_cok[k] ? col / p.Ci : 0;
+        b_ci[k] = (unsigned)(col - tap * p.Ci) * 2u;
+        const int kh = tap / p.ks;
+        b_dh[k] = kh - p.pad;
+        b_dw[k] = tap - kh * p.ks - p.pad;
+        const int m = pix_begin + row;
+        const int n = m / ohw, rem = m - n * ohw;
+        bn[k] = n; boh[k] = rem / p.OW; bow[k] = rem - boh[k] * p.OW;
+    }
+    const unsigned pixb = (unsigned)p.ldx * 2u;
+
+    auto load_tile = [&](int kt, int stage) {
+        unsigned char* as_w = smem + stage * STAGE + wave_u * 1024;
+        unsigned char* bs_w = smem + stage * STAGE + BKP * RBA + wave_u * 1024;
+#pragma unroll
+        for (int k = 0; k < NPA; ++k) {
+            const unsigned v = a_off[k];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(as_w + k * 4096), 16, v, 0, 0, 0);
+            a_off[k] = v == 0xFFFFFFFFu ? v : v + a_step;
+        }
+#pragma unroll
+        for (int k = 0; k < NPB; ++k) {
+            const int m = pix_begin + kt * BKP + (wave + 4 * k) * RPB + lane / CPB;
+            const int xh = boh[k] * p.stride + b_dh[k], xw = bow[k] * p.stride + b_dw[k];
+            const bool ok = b_cok[k] & (m < pix_end) & ((unsigned)xh < (unsigned)p.XH) & ((unsigned)xw < (unsigned)p.XW);
+            const unsigned v = ok ? (unsigned)((bn[k] * p.XH + xh) * p.XW + xw) * pixb + b_ci[k] : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(bs_w + k * 4096), 16, v, 0, 0, 0);
+            bow[k] += BKP;
+            while (bow[k] >= p.OW) { bow[k] -= p.OW; ++boh[k]; }
+            while (boh[k] >= p.OH) { boh[k] -= p.OH; ++bn[k]; }
+        }
+    };
+
+    // ---- MFMA-phase LDS addresses: per-lane constants (the swizzle key of the rows a lane reads does not depend on kk) ----
+    const int q16 = lane & 15, g = lane >> 4;
+    const int prow0 = g * 8 + (q16 >> 2);
+    unsigned a_col[TI], b_col[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int cbyte = (wi * (BCO / 2) + i * 16 + ((q16 & 3) << 2)) * 2;
+        a_col[i] = (unsigned)(prow0 * RBA + ((((cbyte >> 4) ^ (wg_key<RBA>(prow0) << 1)) << 4) | (cbyte & 15)));
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int cbyte = (wj * (BCI / 2) + j * 16 + ((q16 & 3) << 2)) * 2;
+        b_col[j] = (unsigned)(BKP * RBA + prow0 * RBB + ((((cbyte >> 4) ^ (wg_key<RBB>(prow0) << 1)) << 4) | (cbyte & 15)));
+    }
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = pix_end > pix_begin ? (pix_end - pix_begin + BKP - 1) / BKP : 0;
+    if (nkt > 0) load_tile(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1, cur ^ 1);
+        const unsigned char* st = smem + cur * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < BKP / 32; ++kk) {
+            f16x8 a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const unsigned char* ptr = st + a_col[i] + kk * 32 * RBA;
+                const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr));
+                const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr + 4 * RBA));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[i][e] = (f16)lo[e]; a[i][4 + e] = (f16)hi[e]; }
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const unsigned char* ptr = st + b_col[j] + kk * 32 * RBB;
+                const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr));
+                const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr + 4 * RBB));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { b[j][e] = (f16)lo[e]; b[j][4 + e] = (f16)hi[e]; }
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* slab = p.part + (size_t)sp * p.CoRows * p.Ncols;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = col0 + wj * (BCI / 2) + j * 16 + q16;
+            if (col >= p.Ncols) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wi * (BCO / 2) + i * 16 + g * 4 + r;
+                if (co < p.CoRows) slab[(size_t)co * p.Ncols + col] = acc[i][j][r];
+            }
+        }
+}
+
+template <int BCO, int BCI>
+int launch_dma(const WgradParams& p, int split, hipStream_t s) {
+    constexpr int smem = 2 * 64 * (BCO * 2 + BCI * 2);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<BCO, BCI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    WgradParams q = p;
+    q.ncol_tiles = (p.Ncols + BCI - 1) / BCI;
+    q.nco_tiles = (p.CoRows + BCO - 1) / BCO;
+    hipLaunchKernelGGL((wgrad_dma_kernel<BCO, BCI>), dim3(q.ncol_tiles * q.nco_tiles * split), dim3(256), smem, s, q);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T, int BCO, int BCI, bool USE_TR>
 int launch(const WgradParams& p, int split, hipStream_t s) {
     constexpr int BKP = WTraits<T>::BKP;
@@ -245,6 +440,16 @@ int launch(const WgradParams& p, int split, hipStream_t s) {
 }
 
 inline int tile_of(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
+
+inline int dispatch_dma(const WgradParams& p, int split, hipStream_t s) {
+    const int bco = tile_of(p.CoRows), bci = tile_of(p.Ncols);
+#define CY_WD(A, B) \
+    if (bco == A && bci == B) return launch_dma<A, B>(p, split, s);
+    CY_WD(128, 128) CY_WD(128, 64) CY_WD(128, 32) CY_WD(64, 128) CY_WD(64, 64) CY_WD(64, 32) CY_WD(32, 128) CY_WD(32, 64)
+    CY_WD(32, 32)
+#undef CY_WD
+    return CY_ERR_ARG;
+}
 
 template <typename T, bool USE_TR>
 int dispatch(const WgradParams& p, int split, hipStream_t s) {
@@ -369,7 +574,16 @@ extern "C" int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int 
     p.M = N * OH * OW; p.Ncols = ks * ks * Ci; p.CoRows = Co;
     const int bkp = dtype == CY_F16 ? 64 : 32;
     p.pps = (((p.M + split - 1) / split) + bkp - 1) / bkp * bkp;
+    p.x_bytes = 0;
     if (dtype == CY_F32) return dispatch<float, false>(p, split, cy_s(s));
+    {   // direct-to-LDS kernel (CY_WGRAD_DMA=0: register-staged kernel, A/B runs; use_tr = 2 forces the staged kernel too)
+        const char* e = getenv("CY_WGRAD_DMA");
+        const size_t xb = (((size_t)N * XH * XW - 1) * ldx + Ci) * 2, ab = ((size_t)p.M + 128) * lddy * 2;
+        if (use_tr == 1 && !(e && !atoi(e)) && xb < 0xFFFFFF00ull && ab < 0xFFFFFF00ull) {
+            p.x_bytes = (unsigned)xb;
+            return dispatch_dma(p, split, cy_s(s));
+        }
+    }
     return use_tr ? dispatch<f16, true>(p, split, cy_s(s)) : dispatch<f16, false>(p, split, cy_s(s));
 }
 

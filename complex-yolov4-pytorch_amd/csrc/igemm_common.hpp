@@ -1,0 +1,213 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip: generic gather kernel; conv_halo.hip:
+// 3x3 stride-1 kernel that keeps an input patch with its halo resident in LDS): launch parameters, the MFMA
+// fragment helpers and the common epilogue (BN batch statistics, eval-mode affine + activation, packed NHWC stores).
+#pragma once
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace cyk {
+
+struct IgemmParams {
+    const unsigned char* g;
+    const unsigned char* w;
+    unsigned char* o;
+    const float* bias;
+    float* stats;
+    int N, GH, GW, GC, ldg;
+    int OH, OW, OC, ldo;
+    int ks, stride, pad, transposed;
+    int K, M, wrows;
+    int flags;
+    int mtiles, ntiles;
+    // pixel sub-lattice handled by this launch: oh = oh' * oh_mul + oh_off over OHc x OWc (the whole image for
+    // ordinary launches; one parity class for a stride-2 dgrad) and its taps, 2 bits per (kh, kw)
+    int OHc, OWc, oh_mul, oh_off, ow_mul, ow_off;
+    int ntaps;
+    unsigned kh_pack, kw_pack;
+    unsigned g_bytes, w_bytes;  // extents of the gathered view / weight matrix (buffer descriptors: OOB reads return 0)
+    // CY_CONV_AFFINE_ACT epilogue (eval mode): out = act(acc * aff_scale[co] + aff_shift[co]) (+ res)
+    const float* aff_scale;
+    const float* aff_shift;
+    const unsigned char* res;
+    int act, ldres;
+    int dbg_nomma;   // CY_IGEMM_NOMMA bit mask: timing experiments (1 no MFMA, 4 no stores, 8 no stats, 16 one K step)
+    unsigned x_bias;              // igemm_fast_kernel: bytes the gather descriptor's base sits below g (>= any negative row offset)
+    int halo_xbuf, halo_pieces;   // conv_halo.hip: bytes / 8-row pieces of one LDS input patch
+};
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<f16> {
+    static constexpr int KSTEPS = 2;  // MFMA steps per 128-byte LDS row
+    typedef f16x8 frag;
+    __device__ static __forceinline__ frag load(const unsigned char* row_ptr, int kk, int lane) {
+        const int c = (kk * 4 + (lane >> 4)) ^ (lane & 7);
+        return *reinterpret_cast<const frag*>(row_ptr + (c << 4));
+    }
+    __device__ static __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Mma<float> {
+    static constexpr int KSTEPS = 8;
+    typedef float frag;
+    __device__ static __forceinline__ frag load(const unsigned char* row_ptr, int kk, int lane) {
+        const int c = kk ^ (lane & 7);
+        return *reinterpret_cast<const float*>(row_ptr + (c << 4) + ((lane >> 4) << 2));
+    }
+    __device__ static __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+// sum over the 16 lanes of a DPP row (every lane of the row ends up with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
+// Epilogue of a BN-channel x BM-pixel block tile held as 16x16 accumulator fragments:
+// lane holds D[co = cbase + i*16 + (lane>>4)*4 + r][pixel = mbase + j*16 + (lane&15)].
+// NW waves = 2 over channels x NW/2 over pixels.  smem: the block's LDS (free for reuse; SYNC_FIRST adds the barrier
+// that makes it so when the main loop does not end with one).
+template <typename T, int BM, int BN, int NW, bool SYNC_FIRST>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[BN / 32][BM / (8 * NW)], int tm, int tn,
+                                               int lid, unsigned char* smem) {
+    constexpr int NT = NW * 64, WMW = NW / 2, TI = BN / 32, TJ = BM / (16 * WMW);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int ohw = p.OHc * p.OWc;
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // lane holds D[co = cbase + i*16 + (lane>>4)*4 + r][pixel = mbase + j*16 + (lane&15)]
+    const int cbase = tn * BN + wn * (BN / 2) + ((lane >> 4) << 2);
+    const int mbase = tm * BM + wm * (BM / WMW) + (lane & 15);
+    const bool f32out = (p.flags & CY_CONV_BIAS_F32OUT) != 0;
+    const bool accum = (p.flags & CY_CONV_ACCUM) != 0;
+
+    if ((p.flags & CY_CONV_STATS) && !(p.dbg_nomma & 8)) {
+        // per channel (sum, sumsq) of this block's BM pixels: 16-lane DPP row sums -> LDS [wm][2][BN] -> one coalesced
+        // fp32 atomic per (channel, moment) into one of 64 bins (at most blocks/64 adds per address, no fold launch)
+        if constexpr (SYNC_FIRST) __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const float v = (mbase + j * 16 < p.M) ? acc[i][j][r] : 0.f;
+                    s += v;
+                    q += v * v;
+                }
+                s = row16_sum(s);
+                q = row16_sum(q);
+                if ((lane & 3) == r) { sv = s; qv = q; }
+            }
+            // lanes 0..3 of each 16-lane row publish r = lane & 3
+            if ((lane & 15) < 4) {
+                const int cl = wn * (BN / 2) + i * 16 + ((lane >> 4) << 2) + (lane & 3);
+                red[(wm * 2 + 0) * BN + cl] = sv;
+                red[(wm * 2 + 1) * BN + cl] = qv;
+            }
+        }
+        __syncthreads();
+        float* srow = p.stats + (size_t)(lid & 63) * 2 * p.OC;
+        for (int c = tid; c < 2 * BN; c += NT) {
+            const int mom = c / BN, cl = c - mom * BN, co = tn * BN + cl;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) t += red[(2 * w + mom) * BN + cl];
+            if (co < p.OC) atomicAdd(srow + mom * p.OC + co, t);
+        }
+    }
+
+    const bool sublattice = (p.oh_mul | p.ow_mul) != 1 || p.OHc != p.OH || p.OWc != p.OW;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int mj = mbase + j * 16;
+        if (mj >= p.M || (p.dbg_nomma & 4)) continue;
+        int m = mj;
+        if (sublattice) {
+            const int n = mj / ohw, rem = mj - n * ohw;
+            const int ohc = rem / p.OWc;
+            m = (n * p.OH + ohc * p.oh_mul + p.oh_off) * p.OW + (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int co = cbase + i * 16;
+            if (co >= p.OC) continue;
+            f32x4 v = acc[i][j];
+            if (p.flags & CY_CONV_AFFINE_ACT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = min(co + r, p.OC - 1);
+                    const float z = v[r] * p.aff_scale[c] + p.aff_shift[c];
+                    v[r] = p.act == CY_ACT_MISH ? mish_f<sizeof(T) == 2>(z) : (p.act == CY_ACT_LEAKY ? (z > 0.f ? z : 0.1f * z) : z);
+                }
+                if (p.res) {
+                    const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldres + co;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.OC) v[r] += (float)rp[r];
+                }
+            }
+            if (f32out) {
+                float* dst = reinterpret_cast<float*>(p.o) + (size_t)m * p.ldo + co;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < p.OC) {
+                        float t = v[r] + (p.bias ? p.bias[co + r] : 0.f);
+                        if (accum) t += dst[r];
+                        dst[r] = t;
+                    }
+            } else if (sizeof(T) == 2) {
+                f16* dst = reinterpret_cast<f16*>(p.o) + (size_t)m * p.ldo + co;
+                if (co + 3 < p.OC) {
+                    if (accum) {
+                        const f16x4 old = *reinterpret_cast<const f16x4*>(dst);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+                    }
+                    f16x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (f16)v[r];
+                    *reinterpret_cast<f16x4*>(dst) = h;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.OC) dst[r] = (f16)(v[r] + (accum ? (float)dst[r] : 0.f));
+                }
+            } else {
+                float* dst = reinterpret_cast<float*>(p.o) + (size_t)m * p.ldo + co;
+                if (co + 3 < p.OC) {
+                    if (accum) {
+                        const f32x4 old = *reinterpret_cast<const f32x4*>(dst);
+                        v += old;
+                    }
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.OC) dst[r] = v[r] + (accum ? dst[r] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace cyk
+
+// conv_halo.hip: launches the LDS-resident-patch 3x3 kernel when the shape qualifies (*used = 1), else leaves the launch
+// to the generic kernel (*used = 0).
+int cy_halo3x3_try(const cyk::IgemmParams& p, int dtype, hipStream_t s, int* used);

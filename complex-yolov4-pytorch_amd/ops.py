@@ -236,6 +236,11 @@ def nchw_to_nhwc(x, cpad, dt, out=None):
     return out
 
 
+def halo_launches():
+    """Conv launches since load that ran on the LDS-resident-patch 3x3 kernel (cy_halo_launches)."""
+    return int(lib().raw('cy_halo_launches')())
+
+
 def conv_stats_rows(M, OC):
     return lib().raw('cy_conv_stats_rows')(M, OC)
 

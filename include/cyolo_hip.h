@@ -99,6 +99,11 @@ int cy_conv_bn_act_eval(const void* g, int N, int GH, int GW, int GC, int ldg, c
                         int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, const float* scale,
                         const float* shift, int act, const void* res, int ldres, cy_stream_t s);
 
+/* Number of cy_conv_igemm / cy_conv_bn_act_eval calls since load that ran on the LDS-resident-patch kernel
+ * (opt-in with CY_HALO=1: 3x3, stride 1, pad 1, Cin a multiple of 64 f16 / 32 f32 channels, Cout > 32;
+ * csrc/conv_halo.hip); every other call runs on the generic gather kernel.  Diagnostics for tests and profiles. */
+int64_t cy_halo_launches(void);
+
 /* Number of rows (bins) of the stats table cy_conv_igemm adds into (64). */
 int cy_conv_stats_rows(int M, int OC);
 /* Extra rows a partial table needs behind it (0 since the binned-atomics version; kept for ABI stability). */

@@ -76,6 +76,65 @@ def test_conv_forward_and_stats(dt, case):
     torch.testing.assert_close(s[1], (ref.double() ** 2).sum((0, 2, 3)).float(), rtol=1e-3, atol=1e-2)
 
 
+HALO_CASES = [
+    # N, Cin, H, W, Cout, forced tile (None = the library's own choice)
+    (2, 64, 19, 19, 128, '256x128'),
+    (3, 64, 21, 17, 64, '256x64'),      # tiles straddle image boundaries, Cout = 64
+    (2, 128, 13, 29, 160, '128x128'),   # two channel slices (f16), ragged channel tile
+    (1, 192, 38, 38, 64, '128x64'),
+    (5, 64, 76, 76, 128, None),         # 113 blocks of 256 pixels: v4's stride-8 shape
+    (2, 64, 7, 5, 64, '256x64'),        # one partial tile, patch wider than the image
+]
+
+
+@pytest.mark.parametrize('dt', [CY_F16, CY_F32])
+@pytest.mark.parametrize('case', HALO_CASES)
+def test_conv_halo3x3_forward_dgrad(dt, case, monkeypatch):
+    """conv_halo.hip (LDS-resident patch, 3x3 / stride 1) against torch conv2d in float64, forward + BN statistics and
+    dgrad; the generic gather kernel is run on the same call to show the two paths agree."""
+    N, Ci, H, W, Co, tile = case
+    monkeypatch.setenv('CY_HALO', '1')
+    monkeypatch.setenv('CY_HALO_MINBLOCKS', '1')
+    if tile:
+        monkeypatch.setenv('CY_HALO_TILE', tile)
+    x = _round(_rand(N, Ci, H, W, seed=11), dt)
+    w = _round(_rand(Co, Ci, 3, 3, seed=12, scale=1 / math.sqrt(Ci * 9)), dt)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1).float()
+    xv = View.from_nchw(x.to(DEV), dt, ld=Ci + 2 * ops.chunk(dt)).channels(0, Ci)
+    wf, wd = ops.pack_weights(w.to(DEV), Co, Ci, dt)
+    out = View.alloc(N, H, W, Co, dt, ld=Co + 32, zero=True)
+    rows = ops.conv_stats_rows(N * H * W, Co)
+    stats = torch.zeros(rows, 2, Co, device=DEV)
+    n0 = ops.halo_launches()
+    ops.conv_igemm(xv, wf, Co, out, 3, 1, 1, flags=ops.CONV_STATS, stats=stats)
+    assert ops.halo_launches() == n0 + 1
+    torch.testing.assert_close(out.to_nchw().cpu(), ref, **_tol(dt))
+    s = stats.sum(0).cpu()
+    torch.testing.assert_close(s[0], ref.double().sum((0, 2, 3)).float(), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(s[1], (ref.double() ** 2).sum((0, 2, 3)).float(), rtol=1e-3, atol=1e-2)
+    # the generic gather kernel on the same call
+    monkeypatch.setenv('CY_HALO', '0')
+    out2 = View.alloc(N, H, W, Co, dt, zero=True)
+    ops.conv_igemm(xv, wf, Co, out2, 3, 1, 1)
+    assert ops.halo_launches() == n0 + 1
+    torch.testing.assert_close(out2.to_nchw().cpu(), out.to_nchw().cpu(), **_tol(dt))
+    monkeypatch.setenv('CY_HALO', '1')
+    # dgrad (mirrored taps over the [Cin][tap, Cout] pack) + accumulate
+    if Co % (64 if dt == CY_F16 else 32) == 0:
+        dy = _round(_rand(N, Co, H, W, seed=13), dt)
+        wq = _round(_rand(Co, Ci, 3, 3, seed=12, scale=1 / math.sqrt(Co * 9)), dt)
+        _, wd = ops.pack_weights(wq.to(DEV), Co, Ci, dt)
+        gref = torch.nn.grad.conv2d_input((N, Ci, H, W), wq.double(), dy.double(), 1, 1).float()
+        dx = View.alloc(N, H, W, Ci, dt, ld=Ci + 16, zero=True)
+        n1 = ops.halo_launches()
+        ops.conv_igemm(View.from_nchw(dy.to(DEV), dt), wd, Ci, dx, 3, 1, 1, flags=ops.CONV_TRANSPOSED)
+        assert ops.halo_launches() == n1 + 1
+        torch.testing.assert_close(dx.to_nchw().cpu(), gref, **_tol(dt))
+        ops.conv_igemm(View.from_nchw(dy.to(DEV), dt), wd, Ci, dx, 3, 1, 1, flags=ops.CONV_TRANSPOSED | ops.CONV_ACCUM)
+        tol = _tol(dt)
+        torch.testing.assert_close(dx.to_nchw().cpu(), 2 * gref, rtol=2 * tol['rtol'], atol=2 * tol['atol'])
+
+
 @pytest.mark.parametrize('dt', [CY_F16, CY_F32])
 def test_conv_first_layer_padded_input(dt):
     """Layer 0: NCHW fp32 image -> NHWC with 3 channels padded to one 16-byte chunk; K = 9*chunk has a tail."""
