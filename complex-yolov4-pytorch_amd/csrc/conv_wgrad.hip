@@ -553,6 +553,7 @@ extern "C" int cy_conv_wgrad_split(int M, int Co, int Ci, int ks) {
         minpix = f ? atol(f) : 512;
     }
     long split = (target + tiles - 1) / tiles;
+    if (const char* fs = getenv("CY_WGRAD_SPLIT")) split = atol(fs);   // experiments: force the split
     const long max_by_work = (M + minpix - 1) / minpix;  // at least minpix/64 K steps per block
     if (split > max_by_work) split = max_by_work;
     const long slab = (long)Co * ncols * 4;

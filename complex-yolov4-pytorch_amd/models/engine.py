@@ -6,6 +6,8 @@ with its per-block ATen calls, and the autograd graph ``total_loss.backward()`` 
 Memory (288 GB HBM3E): every activation, its raw (pre-BN) twin and its gradient are resident for the
 whole step -- nothing is recomputed, nothing is freed between steps.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -43,7 +45,8 @@ class Engine:
         self.bnvec, self.wf, self.wd = {}, {}, {}
         max_stats = max_bnrows = max_c = 1
         max_wpart = 0
-        self.wsplit, self.wslab_off = {}, {}
+        self.wsplit, self.wslab_off, self.wsplit_cap = {}, {}, {}
+        self._wgrad_tuned = False
         for rec in plan.convs:
             C, M = rec['cout'], N * rec['H'] * rec['W']
             cop, cip = _pad32(C), rec['cin_pad']
@@ -58,9 +61,14 @@ class Engine:
                     max_bnrows = max(max_bnrows, (ops.bn_bwd_rows(M, C, dt) + ops.bn_scratch_rows()) * 2 * C)
             if training:
                 sp = ops.wgrad_split(M, cop, cip, rec['ks'])
+                # room for the split autotuner (first backward) to move away from the heuristic's choice
+                cap = max(1, min((M + 511) // 512, max(2 * sp, sp + 4), 128))
+                while cap > sp and cap * cop * kk * cip * 4 > (512 << 20):
+                    cap -= 1
                 self.wsplit[rec['idx']] = sp
+                self.wsplit_cap[rec['idx']] = max(cap, sp)
                 self.wslab_off[rec['idx']] = max_wpart
-                max_wpart += sp * cop * kk * cip
+                max_wpart += self.wsplit_cap[rec['idx']] * cop * kk * cip
         # binned-atomics tables: zero once, every finaliser leaves its table zeroed for the next layer
         self.stats = torch.zeros(max_stats, **f32)
         self.bnpart = torch.zeros(max_bnrows, **f32)
@@ -69,7 +77,6 @@ class Engine:
         self.wpart = torch.empty(max(max_wpart, 1), **f32)
         self._pack_table = self._pack_key = None
         self._reduce_groups = None
-        import os
         use_side = training and getattr(device, 'type', str(device)) == 'cuda' and os.environ.get('CY_WGRAD_SIDE_STREAM', '1') != '0'
         self.side = torch.cuda.Stream(device=device) if use_side else None
         self.dummy = torch.zeros(16, **f32)
@@ -246,6 +253,8 @@ class Engine:
         assert self.training
         self.grads, self.gout, self.ls = grads, gout_dev, float(loss_scale)
         self.act_scale = float(loss_scale if act_scale is None else act_scale)
+        if not self._wgrad_tuned:
+            self._autotune_wgrad()
         if self._reduce_groups is None or self._reduce_key != grads[next(iter(grads))].data_ptr():
             self._build_reduce_groups()
         flush_at = {g['last']: g for g in self._reduce_groups}
@@ -274,6 +283,46 @@ class Engine:
             if on_module_done is not None:
                 for idx in g['mods']:
                     on_module_done(idx)
+
+    def _autotune_wgrad(self):
+        """Pick the split-K factor of every weight-gradient launch by timing it (once, at the first backward; shapes are
+        static).  The heuristic of cy_conv_wgrad_split is within ~10-25 % of the best split for most layers but the
+        optimum depends on how tiles x split quantises over the CUs; cost = kernel time + the fold's share for the slabs.
+        CY_WGRAD_AUTOTUNE=0 keeps the heuristic."""
+        self._wgrad_tuned = True
+        if getattr(self.device, 'type', str(self.device)) != 'cuda' or os.environ.get('CY_WGRAD_AUTOTUNE', '1') == '0':
+            return
+        memo = {}
+        heads = {id(h['conv']): i for i, h in enumerate(self.plan.heads)}
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rec in self.plan.convs:
+            idx = rec['idx']
+            cop, cip, kk = _pad32(rec['cout']), rec['cin_pad'], rec['ks'] * rec['ks']
+            dy = self.head_tmp[heads[id(rec)]] if id(rec) in heads else self.view(rec['out'], grad=True)
+            xv = self.view(rec['x'])
+            key = (dy.N, dy.H, dy.W, dy.C, dy.ld, xv.H, xv.W, xv.C, xv.ld, rec['ks'], rec['stride'], rec['pad'])
+            if key not in memo:
+                s0, cap = self.wsplit[idx], self.wsplit_cap[idx]
+                cands = sorted({c for c in list(range(max(1, s0 // 3), min(cap, s0 + 8) + 1)) + [cap, (s0 + cap) // 2] if 1 <= c <= cap})
+                if len(cands) > 24:
+                    cands = sorted(set(cands[::max(1, len(cands) // 24)] + [s0]))
+                slab_us = cop * kk * cip * 4 / 2.5e6   # fold: ~2.5 TB/s over the slabs
+                best, best_cost = s0, None
+                off = self.wslab_off[idx]
+                for c in cands:
+                    part = self.wpart[off:off + c * cop * kk * cip]
+                    ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c)
+                    ev0.record()
+                    for _ in range(3):
+                        ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c)
+                    ev1.record()
+                    ev1.synchronize()
+                    cost = ev0.elapsed_time(ev1) * 1e3 / 3 + c * slab_us
+                    if best_cost is None or cost < best_cost:
+                        best, best_cost = c, cost
+                memo[key] = best
+            self.wsplit[idx] = memo[key]
+        self._reduce_groups = None
 
     def _wgrad(self, rec, dy, xv):
         """Weight gradient of one conv.  It is off the critical path of backward (only the optimizer needs it), so it
