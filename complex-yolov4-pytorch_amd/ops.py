@@ -201,7 +201,7 @@ def make_reduce_table(items, device):
     raw, counts = b'', []
     for part, grad, split, corows, cip, ks, Co, Ci in items:
         raw += struct.pack('<QQiiiiii', part.data_ptr(), grad.data_ptr(), split, corows, cip, ks, Co, Ci)
-        counts.append(Co * ks * ks * Ci)
+        counts.append(Co * Ci)   # the fold's work item is a (co, ci) pair (all ks*ks taps)
     desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     blocks = torch.tensor(_block_table(counts), dtype=torch.int32, device=device)
     return desc, blocks
