@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .darknet_utils import parse_cfg, print_cfg
+from .darknet_utils import load_conv, load_conv_bn, parse_cfg, print_cfg, save_conv, save_conv_bn
 from .engine import Engine
 from .graph import Plan, lower_blocks
 from .yolo_layer import YoloLayer
@@ -131,8 +131,51 @@ class Darknet(nn.Module):
         print_cfg(self.blocks)
 
     def load_weights(self, weightfile):
-        raise NotImplementedError('Darknet .weights files are outside the hot path (SURVEY.md section 2 row 2); '
-                                  'use load_state_dict with a reference checkpoint')
+        """Darknet ``.weights`` -> fp32 master parameters and BN running statistics (reference :403-451: int32[5] header,
+        ``seen = header[3]``, then per [convolutional] block in cfg order the flat float32 tensors; a short file stops
+        the walk at the block where it runs out, as the reference's ``start >= buf.size`` check does)."""
+        import numpy as np
+        with open(weightfile, 'rb') as fp:
+            header = np.fromfile(fp, count=5, dtype=np.int32)
+            buf = np.fromfile(fp, dtype=np.float32)
+        self.header = torch.from_numpy(header)
+        self.seen = self.header[3]
+        start, ind = 0, -2
+        for block in self.blocks:
+            if start >= buf.size:
+                break
+            ind += 1
+            if block['type'] != 'convolutional':
+                continue
+            model = self.models[ind]
+            if int(block['batch_normalize']):
+                start = load_conv_bn(buf, start, model[0], model[1])
+            else:
+                start = load_conv(buf, start, model[0])
+        return start
+
+    def save_weights(self, outfile, cutoff=0):
+        """Inverse of load_weights (the reference ships the per-layer writers save_conv_bn / save_conv,
+        darknet_utils.py:209-246, but no model-level method): header then every [convolutional] block up to ``cutoff``
+        (0 = all) in the reference's tensor order."""
+        import numpy as np
+        header = np.zeros(5, dtype=np.int32)
+        h = np.asarray(self.header).astype(np.int32).ravel()
+        header[:min(5, h.size)] = h[:5]
+        header[3] = int(self.seen)
+        last = len(self.blocks) - 1 if cutoff <= 0 else cutoff
+        with open(outfile, 'wb') as fp:
+            header.tofile(fp)
+            ind = -2
+            for block in self.blocks[:last + 1]:
+                ind += 1
+                if block['type'] != 'convolutional':
+                    continue
+                model = self.models[ind]
+                if int(block['batch_normalize']):
+                    save_conv_bn(fp, model[0], model[1])
+                else:
+                    save_conv(fp, model[0])
 
     # ---- plumbing ---------------------------------------------------------------------------------
     def _param_table(self):

@@ -1,4 +1,7 @@
-"""reduce_tensor / create_optimizer -- the two pieces of reference src/utils/train_utils.py the hot path touches."""
+"""reduce_tensor / create_optimizer / checkpoint helpers of reference src/utils/train_utils.py."""
+import copy
+import os
+
 import torch
 
 from ..parallel import reduce_tensor, subdivisions_for  # noqa: F401
@@ -28,3 +31,21 @@ def create_optimizer(configs, model):
     opt.add_param_group({'params': pg1, 'weight_decay': configs.weight_decay})
     opt.add_param_group({'params': pg2})
     return opt
+
+
+def get_saved_state(model, optimizer, lr_scheduler, epoch, configs):
+    """(model state dict, {'epoch', 'configs', 'optimizer', 'lr_scheduler'}) as reference train_utils.py:80-93.  The model
+    state dict holds the fp32 master parameters under the reference's keys, so the checkpoint loads into the reference."""
+    m = model.module if hasattr(model, 'module') else model
+    utils_state_dict = {'epoch': epoch, 'configs': configs, 'optimizer': copy.deepcopy(optimizer.state_dict()),
+                        'lr_scheduler': copy.deepcopy(lr_scheduler.state_dict())}
+    return m.state_dict(), utils_state_dict
+
+
+def save_checkpoint(checkpoints_dir, saved_fn, model_state_dict, utils_state_dict, epoch):
+    """Model_<fn>_epoch_<e>.pth and Utils_<fn>_epoch_<e>.pth, as reference train_utils.py:96-104."""
+    model_save_path = os.path.join(checkpoints_dir, 'Model_{}_epoch_{}.pth'.format(saved_fn, epoch))
+    utils_save_path = os.path.join(checkpoints_dir, 'Utils_{}_epoch_{}.pth'.format(saved_fn, epoch))
+    torch.save(model_state_dict, model_save_path)
+    torch.save(utils_state_dict, utils_save_path)
+    print('save a checkpoint at {}'.format(model_save_path))

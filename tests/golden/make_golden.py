@@ -202,10 +202,104 @@ def gen_nms(ev):
     print('nms.npz', {k: v.shape for k, v in out.items()})
 
 
+def map_case(seed=3):
+    """Detections = the reference's own post_processing_v2 output on synthetic predictions; ground truth = a jittered
+    subset of those detections (true positives at IoU 0.5), some with the wrong class, plus unrelated boxes."""
+    g = torch.Generator().manual_seed(seed)
+    pred = syn.nms_predictions(3, 3000, 160, seed=seed)
+    return pred, g
+
+
+def gen_map(ev):
+    out = {}
+    pred, g = map_case()
+    dets = ev.post_processing_v2(pred.clone(), conf_thresh=0.5, nms_thresh=0.5)
+    rows = []
+    for b, d in enumerate(dets):
+        pick = torch.randperm(d.shape[0], generator=g)[:12]
+        for n, k in enumerate(pick.tolist()):
+            box = d[k, :6].clone()
+            box[:2] += torch.randn(2, generator=g) * (0.5 if n % 3 else 6.0)     # every third one drifts away
+            box[2:4] *= 1.0 + 0.05 * torch.randn(2, generator=g)
+            cls = d[k, -1] if n % 4 else (d[k, -1] + 1) % 3                        # every fourth one has the wrong class
+            rows.append(torch.cat([torch.tensor([float(b), float(cls)]), box]))
+        for _ in range(3):                                                         # unmatched ground truth
+            rows.append(torch.tensor([float(b), float(torch.randint(0, 3, (1,), generator=g)), 40.0 + 500 * float(torch.rand(1, generator=g)),
+                                      40.0 + 500 * float(torch.rand(1, generator=g)), 20.0, 45.0, 0.0, 1.0]))
+    targets = torch.stack(rows)
+    out['targets'] = targets.numpy()
+    for b, d in enumerate(dets):
+        out['det%d' % b] = d.numpy()
+    tps, scores, labels = [], [], []
+    for thr in (0.5, 0.3):
+        stats = ev.get_batch_statistics_rotated_bbox(dets, targets, iou_threshold=thr)
+        for b, (tp, sc, lb) in enumerate(stats):
+            out['tp_thr%d_img%d' % (int(thr * 10), b)] = np.asarray(tp)
+        if thr == 0.5:
+            tps = np.concatenate([s[0] for s in stats]); scores = np.concatenate([s[1].numpy() for s in stats])
+            labels = np.concatenate([s[2].numpy() for s in stats])
+    p, r, ap, f1, cls = ev.ap_per_class(tps, scores, labels, targets[:, 1].numpy())
+    out.update(precision=p, recall=r, ap=ap, f1=f1, ap_class=cls)
+    out['compute_ap_case'] = np.array([ev.compute_ap(np.array([0.1, 0.1, 0.4, 0.7, 0.7, 1.0]), np.array([1.0, 0.5, 0.66, 0.75, 0.6, 0.5]))])
+    np.savez_compressed(os.path.join(HERE, 'map.npz'), **out)
+    print('map.npz', {k: v.shape for k, v in out.items()}, 'AP', ap)
+
+
+def weights_file(path, n_floats, seed=7, seen=12345):
+    """A synthetic Darknet .weights file: header (0, 2, 5, seen, 0) + seeded float32 values (variances made positive by
+    the consumer is not needed: load_weights copies verbatim)."""
+    rs = np.random.RandomState(seed)
+    with open(path, 'wb') as fp:
+        np.array([0, 2, 5, seen, 0], dtype=np.int32).tofile(fp)
+        rs.standard_normal(n_floats).astype(np.float32).tofile(fp)
+
+
+def gen_weights(d2p):
+    """Reference Darknet.load_weights on the mini cfg: per state-dict entry (sum, sum of squares, first, last)."""
+    import tempfile
+    from tests.util import mini_cfg_path
+    cfg = mini_cfg_path()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = d2p.Darknet(cfgfile=cfg, use_giou_loss=True)
+    n = sum(v.numel() for k, v in model.state_dict().items() if 'num_batches_tracked' not in k)
+    out = {'n_floats': np.array([n])}
+    # floats of the first five [convolutional] blocks: a file that ends on a block boundary loads silently (the rest
+    # of the model keeps its values)
+    sd = model.state_dict()
+    prefix = sum(v.numel() for k, v in sd.items() if 'num_batches_tracked' not in k and int(k.split('.')[1]) <= 6)
+    out['prefix_floats'] = np.array([prefix])
+    for tag, count in (('full', n), ('short', n // 2), ('prefix', prefix)):
+        path = os.path.join(tempfile.gettempdir(), 'cyolo_golden_%s.weights' % tag)
+        weights_file(path, count)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model = d2p.Darknet(cfgfile=cfg, use_giou_loss=True)
+        torch.manual_seed(0)
+        for p in model.parameters():
+            p.data.fill_(0.25)
+        try:
+            model.load_weights(path)
+        except Exception as e:      # a file that ends inside a tensor makes the reference raise
+            out[tag + '_error'] = np.array([1]); print('reference raised on', tag, type(e).__name__)
+            continue
+        out[tag + '_seen'] = np.array([int(model.seen)])
+        for k, v in model.state_dict().items():
+            if 'num_batches_tracked' in k:
+                continue
+            v = v.double().reshape(-1)
+            out['%s/%s' % (tag, k)] = np.array([float(v.sum()), float((v * v).sum()), float(v[0]), float(v[-1])])
+    np.savez_compressed(os.path.join(HERE, 'weights.npz'), **out)
+    print('weights.npz', len(out), 'entries, floats', n)
+
+
 if __name__ == '__main__':
     d2p, yl, iou, cal, ev = import_reference()
     torch.set_num_threads(8)
     gen_geometry(iou, cal)
     gen_head(yl)
     gen_nms(ev)
-    gen_darknet(d2p)
+    gen_map(ev)
+    gen_weights(d2p)
+    if '--skip-darknet' not in sys.argv:
+        gen_darknet(d2p)

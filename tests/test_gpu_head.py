@@ -172,3 +172,26 @@ def test_yolo_head_rejects_out_of_range_target():
     tg[0, 2] = 1.0   # x == 1.0 indexes cell G (reference raises IndexError; we flag and skip the row)
     _, met, _ = _run_head(head_input(2, 19, 0), tg, _anchors((6, 7, 8)), True)
     assert met[19] == 1
+
+
+def test_map_batch_statistics_golden(golden):
+    """get_batch_statistics_rotated_bbox with device IoUs against the reference's true-positive flags (exact)."""
+    from complex_yolov4_pytorch_amd.utils.evaluation_utils import ap_per_class, get_batch_statistics_rotated_bbox
+    g = golden('map')
+    dets = [torch.from_numpy(g['det%d' % b]) for b in range(3)]
+    targets = torch.from_numpy(g['targets'])
+    for thr in (0.5, 0.3):
+        stats = get_batch_statistics_rotated_bbox(dets, targets, iou_threshold=thr)
+        assert len(stats) == 3
+        for b, (tp, sc, lb) in enumerate(stats):
+            np.testing.assert_array_equal(tp, g['tp_thr%d_img%d' % (int(thr * 10), b)])
+            np.testing.assert_array_equal(sc.numpy(), g['det%d' % b][:, 6])
+            np.testing.assert_array_equal(lb.numpy(), g['det%d' % b][:, -1])
+    stats = get_batch_statistics_rotated_bbox(dets, targets, iou_threshold=0.5)
+    tp = np.concatenate([s[0] for s in stats]); sc = np.concatenate([s[1].numpy() for s in stats])
+    lb = np.concatenate([s[2].numpy() for s in stats])
+    _, _, ap, _, cls = ap_per_class(tp, sc, lb, targets[:, 1].numpy())
+    np.testing.assert_allclose(ap, g['ap'], rtol=1e-12)
+    # device detections straight from post_processing_v2 (None entries skipped), no targets for image 1
+    stats = get_batch_statistics_rotated_bbox([None, dets[1].to(DEV)], targets[targets[:, 0] == 0], 0.5)
+    assert len(stats) == 1 and stats[0][0].sum() == 0
