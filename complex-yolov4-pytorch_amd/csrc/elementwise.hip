@@ -412,6 +412,31 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const cy_adam_desc* __r
     }
 }
 
+// torch.optim.SGD (dampening 0): g += wd * p;  buf = first step ? g : momentum * buf + g;  p -= lr * (nesterov ? g + momentum * buf : buf)
+__global__ void __launch_bounds__(256) sgd_multi_kernel(const cy_adam_desc* __restrict__ desc, const int* __restrict__ blocks,
+                                                       float momentum, int nesterov, int first_step, int zero_grad,
+                                                       AdamGroups grp) {
+    const cy_adam_desc d = desc[blocks[2 * blockIdx.x]];
+    const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
+    const float lr = grp.lr[d.group & 7], wdecay = grp.wd[d.group & 7];
+#pragma unroll
+    for (int it = 0; it < CY_MULTI_ELEMS / 256; ++it) {
+        const long i = first + it * 256 + threadIdx.x;
+        if (i >= d.n) break;
+        float g = d.g[i];
+        const float p = d.p[i];
+        if (wdecay != 0.f) g += wdecay * p;
+        float upd = g;
+        if (momentum != 0.f) {
+            const float buf = first_step ? g : momentum * d.m[i] + g;
+            d.m[i] = buf;
+            upd = nesterov ? g + momentum * buf : buf;
+        }
+        d.p[i] = p - lr * upd;
+        if (zero_grad) d.g[i] = 0.f;
+    }
+}
+
 __global__ void bias_grad_kernel(const float* __restrict__ d, long M, int C, float scale,
                                  const float* __restrict__ scale_dev, float* gbias) {
     if (scale_dev) scale *= *scale_dev;
@@ -729,6 +754,23 @@ extern "C" int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, in
     }
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, beta1, beta2, eps, bias_corr1,
                        bias_corr2, zero_grad, grp);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_sgd_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float momentum, int nesterov,
+                            int first_step, int zero_grad, const float* group_lr_host, const float* group_wd_host, int ngroups,
+                            cy_stream_t s) {
+    CY_ENTER();
+    if (!desc || !blocks || nblocks < 1 || momentum < 0.f) return CY_ERR_ARG;
+    if (!group_lr_host || !group_wd_host || ngroups < 1 || ngroups > 8) return CY_ERR_ARG;
+    AdamGroups grp;
+    for (int i = 0; i < 8; ++i) {
+        grp.lr[i] = i < ngroups ? group_lr_host[i] : 0.f;
+        grp.wd[i] = i < ngroups ? group_wd_host[i] : 0.f;
+    }
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, momentum, nesterov, first_step,
+                       zero_grad, grp);
     CY_LAUNCH_CHECK();
     return 0;
 }

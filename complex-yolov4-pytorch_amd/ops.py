@@ -223,6 +223,11 @@ def make_adam_table(items, device):
     return desc, blocks
 
 
+def sgd_multi(desc, blocks, momentum, nesterov, first_step, lrs, wds, zero_grad=False):
+    lib().call('cy_sgd_multi', _p(desc), _p(blocks), blocks.shape[0], float(momentum), int(nesterov), int(first_step),
+               int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _stream())
+
+
 def adam_multi(desc, blocks, beta1, beta2, eps, bc1, bc2, lrs, wds, zero_grad=False):
     lib().call('cy_adam_multi', _p(desc), _p(blocks), blocks.shape[0], float(beta1), float(beta2), float(eps), float(bc1),
                float(bc2), int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _stream())
@@ -455,4 +460,25 @@ def probe_tr16():
     _require_gpu()
     out = torch.zeros(64, 4, dtype=torch.int16, device='cuda')
     lib().call('cy_probe_tr16', _p(out), _stream())
+    return out
+
+
+def bev_workspace(H, W, device='cuda'):
+    """Zeroed workspace for bev_rasterize (the kernel leaves it zeroed, so it can be reused frame after frame)."""
+    return torch.zeros(int(lib().raw('cy_bev_workspace')(H, W)), dtype=torch.uint8, device=device)
+
+
+def bev_rasterize(points, bounds, disc, H, W, workspace, out=None, zshift=None, max_height=None):
+    """points: float32 [n,4] device tensor (x, y, z, intensity); bounds = (minX, maxX, minY, maxY, minZ, maxZ).
+    zshift / max_height default to minZ / |maxZ - minZ| (raw points).  -> float32 [3,H,W] (intensity, height, density)."""
+    _require_gpu()
+    check_device_tensor(points, 'points')
+    pts = points.contiguous()
+    assert pts.dtype == torch.float32 and pts.dim() == 2 and pts.shape[1] == 4
+    if out is None:
+        out = torch.empty(3, H, W, dtype=torch.float32, device=pts.device)
+    zshift = bounds[4] if zshift is None else zshift
+    max_height = abs(bounds[5] - bounds[4]) if max_height is None else max_height
+    lib().call('cy_bev_rasterize', _p(pts) if pts.shape[0] else None, pts.shape[0], *[float(v) for v in bounds], float(zshift),
+               float(max_height), float(disc), H, W, _p(workspace), _p(out), _stream())
     return out

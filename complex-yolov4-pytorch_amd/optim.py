@@ -1,4 +1,5 @@
-"""FusedAdam: torch.optim.Adam semantics, one HIP launch per step for the whole model (cy_adam_multi).
+"""FusedAdam / FusedSGD: torch.optim.Adam / torch.optim.SGD semantics, one HIP launch per step for the whole model
+(cy_adam_multi / cy_sgd_multi).
 
 SURVEY.md section 8f #3 ("next": optimizer step fused).  Same constructor / param_groups / state_dict surface as
 torch.optim.Adam for the options the reference uses (reference src/utils/train_utils.py:21-50: Adam(lr) with a
@@ -48,4 +49,49 @@ class FusedAdam(torch.optim.Optimizer):
         ops.adam_multi(self._table[0], self._table[1], b1, b2, self.param_groups[0]['eps'], 1 - b1 ** self._steps,
                        1 - b2 ** self._steps, [g['lr'] for g in self.param_groups],
                        [g['weight_decay'] for g in self.param_groups], zero_grad=zero_grad)
+        return loss
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD(lr, momentum, nesterov, weight_decay) with dampening 0 in one launch (cy_sgd_multi); the
+    reference's ``optimizer_type == 'sgd'`` choice (train_utils.py:35-37)."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, nesterov=False, weight_decay=0.0):
+        if nesterov and momentum <= 0:
+            raise ValueError('Nesterov momentum requires a momentum and zero dampening')
+        super().__init__(params, dict(lr=lr, momentum=momentum, nesterov=nesterov, weight_decay=weight_decay, dampening=0))
+        self._table = self._key = None
+        self._steps = 0
+
+    def _build(self):
+        items, fresh = [], False
+        for gi, group in enumerate(self.param_groups):
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if 'momentum_buffer' not in st:
+                    st['momentum_buffer'] = torch.zeros_like(p.data)
+                    fresh = True
+                items.append((p.data, p.grad, st['momentum_buffer'], st['momentum_buffer'], gi))
+        key = tuple((i[0].data_ptr(), i[1].data_ptr(), i[4]) for i in items)
+        if key != self._key:
+            self._table = ops.make_adam_table(items, items[0][0].device) if items else None
+            self._key = key
+        return fresh
+
+    @torch.no_grad()
+    def step(self, closure=None, zero_grad=False):
+        loss = closure() if closure is not None else None
+        fresh = self._build()
+        if self._table is None:
+            return loss
+        g0 = self.param_groups[0]
+        for g in self.param_groups:
+            assert g['momentum'] == g0['momentum'] and g['nesterov'] == g0['nesterov'], 'momentum/nesterov must be shared'
+        assert len(self.param_groups) <= 8
+        first = self._steps == 0 or fresh
+        self._steps += 1
+        ops.sgd_multi(self._table[0], self._table[1], g0['momentum'], g0['nesterov'], first,
+                      [g['lr'] for g in self.param_groups], [g['weight_decay'] for g in self.param_groups], zero_grad=zero_grad)
         return loss

@@ -19,7 +19,11 @@ def create_optimizer(configs, model):
         else:
             pg0.append(v)
     if configs.optimizer_type == 'sgd':
-        opt = torch.optim.SGD(pg0, lr=configs.lr, momentum=configs.momentum, nesterov=True)
+        if getattr(configs, 'fused_optimizer', True) and pg0 and pg0[0].is_cuda:
+            from ..optim import FusedSGD
+            opt = FusedSGD(pg0, lr=configs.lr, momentum=configs.momentum, nesterov=True)
+        else:
+            opt = torch.optim.SGD(pg0, lr=configs.lr, momentum=configs.momentum, nesterov=True)
     elif configs.optimizer_type == 'adam':
         if getattr(configs, 'fused_optimizer', True) and pg0 and pg0[0].is_cuda:
             from ..optim import FusedAdam

@@ -75,6 +75,12 @@ typedef struct {
 int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2, float eps,
                   float bias_corr1, float bias_corr2, int zero_grad, const float* group_lr_host,
                   const float* group_wd_host, int ngroups, cy_stream_t s);
+/* Fused multi-tensor SGD with momentum / Nesterov (torch.optim.SGD semantics, dampening 0): the reference's other
+ * optimizer choice (src/utils/train_utils.py:35-37: SGD(lr, momentum, nesterov=True)).  Uses cy_adam_desc with `m` as the
+ * momentum buffer (`v` unused, may be NULL); first_step != 0 initialises the buffer with the gradient as torch does. */
+int cy_sgd_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float momentum, int nesterov, int first_step,
+                 int zero_grad, const float* group_lr_host, const float* group_wd_host, int ngroups, cy_stream_t s);
+
 
 /* NCHW fp32 image batch [N][C][H][W] -> NHWC `dtype` view with CPad channels (extra channels zero).
  * (reference: the imgs tensor handed to Darknet.forward, darknet2pytorch.py:162) */
@@ -240,6 +246,21 @@ int cy_pp2_merge(const float* pred, int B, int N, int C, const int32_t* cand_idx
  * relies on: out[64][4] = what each lane receives from ds_read_b64_tr_b16 over a 16x16 u16 tile
  * holding its own linear index. */
 int cy_probe_tr16(uint16_t* out, cy_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * LiDAR -> bird's-eye-view rasteriser (reference removePoints + makeBVFeature,
+ * src/data_process/kitti_bev_utils.py:18-76, called from kitti_dataset.py:81-82,105-106)
+ * ---------------------------------------------------------------------------------------------- */
+/* Bytes of zero-initialised device workspace cy_bev_rasterize needs for an H x W map (it leaves it zeroed). */
+int64_t cy_bev_workspace(int H, int W);
+/* points: n x (x, y, z, intensity) float32 on the device, 16-byte aligned.  Points outside the closed box
+ * [minX,maxX] x [minY,maxY] x [minZ,maxZ] are dropped; pixel (xi, yi) = (floor(x / disc), trunc(floor(y / disc) + (W+1)/2)),
+ * float32 arithmetic as numpy does it; bins xi == H / yi == W are cropped like the reference's [:H, :W].
+ * out: float32 [3][H][W] = intensity of the highest point, its (z - zshift) / max_height, min(1, log(count+1)/log 64);
+ * zshift = minZ and max_height = |maxZ - minZ| reproduce removePoints + makeBVFeature on raw points.
+ * Equal heights in one pixel: the point that comes first in `points` wins (the reference's stable sort). */
+int cy_bev_rasterize(const float* points, int n, float minX, float maxX, float minY, float maxY, float minZ, float maxZ,
+                     float zshift, float max_height, float disc, int H, int W, void* workspace, float* out, cy_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -245,6 +245,41 @@ def gen_map(ev):
     print('map.npz', {k: v.shape for k, v in out.items()}, 'AP', ap)
 
 
+def lidar_points(n, seed=11):
+    """Synthetic KITTI-like scan: float32 (x, y, z, intensity); ~15 % outside the BEV box, clusters that put many points
+    in one pixel, exact duplicates of heights inside a pixel (tie rule) and points exactly on the box faces."""
+    rs = np.random.RandomState(seed)
+    p = np.empty((n, 4), dtype=np.float32)
+    p[:, 0] = rs.uniform(-5, 55, n); p[:, 1] = rs.uniform(-28, 28, n); p[:, 2] = rs.uniform(-3.2, 1.6, n)
+    p[:, 3] = rs.uniform(0, 1, n)
+    k = n // 5                                           # clusters: 40 points around each of k/40 centres
+    c = rs.randint(0, n, k // 40)
+    p[:k] = np.repeat(p[c], 40, axis=0)[:k]
+    p[:k, :2] += rs.normal(0, 0.03, (k, 2)).astype(np.float32)
+    p[:k, 2] += rs.normal(0, 0.2, k).astype(np.float32)
+    p[:k, 3] = rs.uniform(0, 1, k)
+    t = n // 50                                          # ties: copy position AND height, new intensity
+    src = rs.randint(k, n, t); dst = rs.randint(k, n, t)
+    p[dst, :3] = p[src, :3]
+    p[-6:, 0] = [0.0, 50.0, 25.0, 25.0, 10.0, 10.0]      # box faces (x = 50 and y = 25 land in the cropped bins)
+    p[-6:, 1] = [0.0, 0.0, -25.0, 25.0, 3.0, 3.0]
+    p[-6:, 2] = [0.0, 0.0, 0.0, 0.0, -2.73, 1.27]
+    return p
+
+
+def gen_bev():
+    import data_process.kitti_bev_utils as bev
+    import config.kitti_config as cnf
+    pts = lidar_points(30000)
+    b = bev.removePoints(pts.copy(), cnf.boundary)
+    rgb = bev.makeBVFeature(b, cnf.DISCRETIZATION, cnf.boundary)
+    rgb32 = rgb.astype(np.float32)
+    nz = np.flatnonzero(rgb32.reshape(3, -1).any(0))
+    np.savez_compressed(os.path.join(HERE, 'bev.npz'), kept=np.array([b.shape[0]]), pixels=nz.astype(np.int32),
+                        values=rgb32.reshape(3, -1)[:, nz], shape=np.array(rgb.shape))
+    print('bev.npz: kept', b.shape[0], 'of', pts.shape[0], 'points,', nz.size, 'occupied pixels, max count density', rgb[2].max())
+
+
 def weights_file(path, n_floats, seed=7, seen=12345):
     """A synthetic Darknet .weights file: header (0, 2, 5, seen, 0) + seeded float32 values (variances made positive by
     the consumer is not needed: load_weights copies verbatim)."""
@@ -301,5 +336,6 @@ if __name__ == '__main__':
     gen_nms(ev)
     gen_map(ev)
     gen_weights(d2p)
+    gen_bev()
     if '--skip-darknet' not in sys.argv:
         gen_darknet(d2p)

@@ -160,3 +160,43 @@ def test_v4_fp16_1024_step_is_finite():
     loss.backward()
     assert tuple(out.shape) == (2, 64512, 10)                 # 64,512 boxes per image at 1024^2
     assert torch.isfinite(loss).all() and torch.isfinite(model.flat_grad).all()
+
+
+def test_bev_rasteriser_golden_and_edges(golden):
+    """cy_bev_rasterize through the kitti_bev_utils drop-ins against the reference's maps: occupied pixels, intensity and
+    height bit-exact (including the equal-height tie rule and the box faces), density to 1 ulp of float32."""
+    import numpy as np
+    import complex_yolov4_pytorch_amd.config.kitti_config as cnf
+    from complex_yolov4_pytorch_amd.data_process import kitti_bev_utils as bev
+    from oracle import bev_ref
+    from tests.golden.make_golden import lidar_points
+    g = golden('bev')
+    pts = lidar_points(30000)
+    ref = np.zeros((3, 608 * 608), dtype=np.float32)
+    ref[:, g['pixels']] = g['values']
+    ref = ref.reshape(3, 608, 608)
+    # raw points on the device, one fused pass
+    got = bev.makeBVFeature(torch.from_numpy(pts).cuda(), cnf.DISCRETIZATION, cnf.boundary)
+    assert got.is_cuda and got.dtype == torch.float32 and got.shape == (3, 608, 608)
+    got = got.cpu().numpy()
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_allclose(got[2], ref[2], rtol=2e-7, atol=0)
+    np.testing.assert_array_equal(got[2] != 0, ref[2] != 0)
+    # the reference's two-call form on numpy arrays: numpy float64 out
+    b = bev.removePoints(pts.copy(), cnf.boundary)
+    assert b.shape[0] == int(g['kept'][0])
+    got2 = bev.makeBVFeature(b, cnf.DISCRETIZATION, cnf.boundary)
+    assert isinstance(got2, np.ndarray) and got2.dtype == np.float64
+    np.testing.assert_array_equal(got2.astype(np.float32)[:2], ref[:2])
+    # the workspace is left clean: a second frame is not polluted by the first; empty cloud -> zeros
+    again = bev.makeBVFeature(torch.from_numpy(pts).cuda(), cnf.DISCRETIZATION, cnf.boundary).cpu().numpy()
+    np.testing.assert_array_equal(again, got)
+    empty = bev.makeBVFeature(torch.zeros(0, 4).cuda(), cnf.DISCRETIZATION, cnf.boundary)
+    assert float(empty.abs().sum()) == 0.0
+    # a full-size scan (120k points, KITTI-like) against the oracle
+    big = lidar_points(120000, seed=5)
+    o = bev_ref.make_bv_feature(bev_ref.remove_points(big.copy(), cnf.boundary), cnf.DISCRETIZATION, cnf.boundary).astype(np.float32)
+    gb = bev.makeBVFeature(torch.from_numpy(big).cuda(), cnf.DISCRETIZATION, cnf.boundary).cpu().numpy()
+    np.testing.assert_array_equal(gb[:2], o[:2])
+    np.testing.assert_allclose(gb[2], o[2], rtol=2e-7, atol=0)

@@ -384,6 +384,35 @@ def test_fused_adam_matches_torch_adam():
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize('nesterov', [True, False])
+def test_fused_sgd_matches_torch_sgd(nesterov):
+    """cy_sgd_multi vs torch.optim.SGD(momentum, nesterov) with the reference's three parameter groups, 5 steps."""
+    from complex_yolov4_pytorch_amd.optim import FusedSGD
+    shapes = [(64, 32, 3, 3), (64,), (64,), (30, 256, 1, 1), (30,), (1000,)]
+    ref_p = [_rand(*s, seed=170 + i).to(DEV).requires_grad_(True) for i, s in enumerate(shapes)]
+    my_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    ref = torch.optim.SGD(ref_p[:2], lr=1e-2, momentum=0.949, nesterov=nesterov)
+    ref.add_param_group({'params': ref_p[2:4], 'weight_decay': 5e-4})
+    ref.add_param_group({'params': ref_p[4:]})
+    mine = FusedSGD(my_p[:2], lr=1e-2, momentum=0.949, nesterov=nesterov)
+    mine.add_param_group({'params': my_p[2:4], 'weight_decay': 5e-4})
+    mine.add_param_group({'params': my_p[4:]})
+    for step in range(5):
+        for i, (a, b) in enumerate(zip(ref_p, my_p)):
+            g = _rand(*a.shape, seed=300 + 10 * step + i).to(DEV)
+            a.grad = g.clone()
+            b.grad = g.clone()
+        if step == 3:
+            for opt in (ref, mine):
+                opt.param_groups[0]['lr'] = 3e-3
+        ref.step()
+        mine.step()
+    for a, b in zip(ref_p, my_p):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
+    for a, b in zip(ref_p, my_p):
+        torch.testing.assert_close(mine.state[b]['momentum_buffer'], ref.state[a]['momentum_buffer'], rtol=2e-5, atol=2e-6)
+
+
 @pytest.mark.parametrize('dt', [CY_F16, CY_F32])
 @pytest.mark.parametrize('act', ['mish', 'leaky', 'linear'])
 def test_conv_bn_act_eval_fused(dt, act):
