@@ -183,7 +183,8 @@ def main():
                             launches_per_step=ig['launches'] // 2, avg_launch_us=round(1e3 * ig['ms'] / ig['launches'], 2),
                             hbm_gbs_algorithmic=round(ig['bytes'] / (ig['ms'] * 1e-3) / 1e9, 1),
                             algorithmic_bytes_per_launch=round(ig['bytes'] / ig['launches']),
-                            measured='HIP events around every launch of the kernel on its launch stream, 2 extra single-stream steps after the timed region')
+                            measured='HIP events around every launch of the kernel on its launch stream, minus the duration of an empty event bracket; 2 extra single-stream steps after the timed region',
+                            avg_launch_us_with_event_overhead=round(1e3 * ig['ms_raw'] / ig['launches'], 2))
             wg = summ.get('wgrad')
             if wg:
                 roofline['wgrad_kernel'] = dict(achieved=round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12, 2), unit='TFLOP/s',

@@ -24,13 +24,29 @@ class LaunchProfiler:
     def bracket(self, kind, flops, nbytes):
         return _Bracket(self, kind, flops, nbytes)
 
+    def bracket_overhead_ms(self, n=64):
+        """Median duration of an EMPTY bracket (event record -> event record with nothing in between) on the current
+        stream: what the two event records add to every measured launch."""
+        pairs = []
+        for _ in range(n):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            e.record()
+            pairs.append((s, e))
+        torch.cuda.synchronize()
+        t = sorted(s.elapsed_time(e) for s, e in pairs)
+        return t[len(t) // 2]
+
     def summary(self):
         torch.cuda.synchronize()
+        over = self.bracket_overhead_ms()
         out = {}
         for kind, flops, nbytes, s, e in self.records:
-            d = out.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d = out.setdefault(kind, dict(launches=0, ms=0.0, ms_raw=0.0, flops=0.0, bytes=0.0))
             d['launches'] += 1
-            d['ms'] += s.elapsed_time(e)
+            t = s.elapsed_time(e)
+            d['ms_raw'] += t
+            d['ms'] += max(t - over, 0.0)
             d['flops'] += flops
             d['bytes'] += nbytes
         return out
@@ -201,7 +217,7 @@ def make_reduce_table(items, device):
     raw, counts = b'', []
     for part, grad, split, corows, cip, ks, Co, Ci in items:
         raw += struct.pack('<QQiiiiii', part.data_ptr(), grad.data_ptr(), split, corows, cip, ks, Co, Ci)
-        counts.append(Co * Ci)   # the fold's work item is a (co, ci) pair (all ks*ks taps)
+        counts.append(Co * ks * ks * Ci)
     desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     blocks = torch.tensor(_block_table(counts), dtype=torch.int32, device=device)
     return desc, blocks

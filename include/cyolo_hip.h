@@ -48,8 +48,7 @@ int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad, int CiPad
 
 /* Table-driven variants: ONE launch for every conv of the network (the per-layer calls above cost a kernel boundary
  * each, ~110 per step).  `desc` is a device array of cy_pack_desc / cy_reduce_desc; `blocks` a device array of
- * (descriptor index, first element / 256) pairs, one per 256-thread block covering CY_MULTI_ELEMS elements
- * (pack, adam: tensor elements; reduce: (co, ci) pairs, each with its ks*ks taps). */
+ * (descriptor index, first element / 256) pairs, one per 256-thread block covering CY_MULTI_ELEMS elements. */
 typedef struct {
     const float* w; void* wf; void* wd;
     int Co, Ci, ks, CoPad, CiPad, pad_;
