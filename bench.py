@@ -160,19 +160,23 @@ def main():
     final_loss = float(loss.detach().reshape(-1)[0])
 
     roofline = None
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline:
         # exclusive kernel durations: the probe steps issue the weight-gradient kernels on the main stream (in the timed
-        # region they overlap the dgrad/BN kernels from a side stream, which stretches every kernel's own duration)
+        # region they overlap the dgrad/BN kernels from a side stream, which stretches every kernel's own duration).
+        # EVERY rank runs the probe steps (a step contains the gradient all-reduce); only rank 0 brackets its launches.
         sides = [(e, e.side) for e in model._engines.values()]
         for e, _ in sides:
             e.side = None
-        ops.PROFILER = ops.LaunchProfiler()
+        if rank == 0:
+            ops.PROFILER = ops.LaunchProfiler()
         for _ in range(2):
             step()
-        summ = ops.PROFILER.summary()
+        summ = ops.PROFILER.summary() if rank == 0 else {}
         ops.PROFILER = None
         for e, sd in sides:
             e.side = sd
+        sync()
+    if roofline is None and rank == 0 and not a.no_roofline:
         ig = summ.get('igemm')
         if ig:
             ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12
