@@ -223,14 +223,77 @@ __global__ void slice_kernel(const T* __restrict__ x, int ldx, const T* __restri
     }
 }
 
+// Max pooling as two separable passes (rows, then columns).  Exactly torch's result including its tie rule (first
+// maximum in row-major window order = first row that holds the maximum, first column inside that row), with k + k loads
+// per output instead of k * k (SPP: k = 5 / 9 / 13).  The per-pass tap indices are kept for the backward pass, which
+// gathers through the same two stages instead of scattering with atomics (a local maximum is the arg-max of up to k*k
+// windows: that many same-address atomics).
+template <int CH>
+__device__ __forceinline__ void store_bytes(uint8_t* dst, const int* v) {
+    if constexpr (CH == 8) {
+        unsigned long long w = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w |= (unsigned long long)(v[e] & 0xFF) << (8 * e);
+        *reinterpret_cast<unsigned long long*>(dst) = w;
+    } else {
+        unsigned w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w |= (unsigned)(v[e] & 0xFF) << (8 * e);
+        *reinterpret_cast<unsigned*>(dst) = w;
+    }
+}
+template <int CH>
+__device__ __forceinline__ void load_bytes(const uint8_t* src, int* v) {
+    if constexpr (CH == 8) {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long*>(src);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (int)((w >> (8 * e)) & 0xFF);
+    } else {
+        const unsigned w = *reinterpret_cast<const unsigned*>(src);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (int)((w >> (8 * e)) & 0xFF);
+    }
+}
+
+// pass 1: m1[n][h][ow] = max_b x[n][h][ow*stride - pad + b], tap index b1
 template <typename T>
-__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int ldx, T* __restrict__ y,
-                                   int OH, int OW, int ldy, int k, int stride, int pad, uint8_t* __restrict__ amax) {
+__global__ void maxpool_rows_kernel(const T* __restrict__ x, int N, int H, int W, int C, int ldx, T* __restrict__ m1, int OW,
+                                    int k, int stride, int pad, uint8_t* __restrict__ b1) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH;
+    const long total = (long)N * H * OW * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / cpr;                       // (n, h, ow)
+        const int ck = (int)(i - p * cpr);
+        const int ow = (int)(p % OW);
+        const long nh = p / OW;                       // n * H + h
+        float best[CH];
+        int arg[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+        for (int b = 0; b < k; ++b) {
+            const int w = ow * stride - pad + b;
+            if (w < 0 || w >= W) continue;
+            float f[CH];
+            chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(x + (nh * W + w) * ldx + ck * CH), f);
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+                if (f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; arg[e] = b; }
+        }
+        *reinterpret_cast<u32x4*>(m1 + p * C + ck * CH) = f32_to_chunk<T>(best);
+        if (b1) store_bytes<CH>(b1 + p * C + ck * CH, arg);
+    }
+}
+
+// pass 2: y[n][oh][ow] = max_a m1[n][oh*stride - pad + a][ow], tap index a1
+template <typename T>
+__global__ void maxpool_cols_kernel(const T* __restrict__ m1, int N, int H, int C, T* __restrict__ y, int OH, int OW, int ldy,
+                                    int k, int stride, int pad, uint8_t* __restrict__ a1) {
     constexpr int CH = Elem<T>::CH;
     const int cpr = C / CH;
     const long total = (long)N * OH * OW * cpr;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long p = i / cpr;
+        const long p = i / cpr;                       // (n, oh, ow)
         const int ck = (int)(i - p * cpr);
         const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), n = (int)(p / ((long)OW * OH));
         float best[CH];
@@ -240,36 +303,88 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W,
         for (int a = 0; a < k; ++a) {
             const int h = oh * stride - pad + a;
             if (h < 0 || h >= H) continue;
-            for (int b = 0; b < k; ++b) {
-                const int w = ow * stride - pad + b;
-                if (w < 0 || w >= W) continue;
-                float f[CH];
-                chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(x + ((long)(n * H + h) * W + w) * ldx + ck * CH), f);
+            float f[CH];
+            chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(m1 + (((long)n * H + h) * OW + ow) * C + ck * CH), f);
 #pragma unroll
-                for (int e = 0; e < CH; ++e)
-                    if (f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; arg[e] = a * k + b; }
-            }
+            for (int e = 0; e < CH; ++e)
+                if (f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; arg[e] = a; }
         }
         *reinterpret_cast<u32x4*>(y + p * ldy + ck * CH) = f32_to_chunk<T>(best);
-        if (amax) {
-#pragma unroll
-            for (int e = 0; e < CH; ++e) amax[p * C + ck * CH + e] = (uint8_t)arg[e];
-        }
+        if (a1) store_bytes<CH>(a1 + p * C + ck * CH, arg);
     }
 }
 
+// backward pass 1: dm1[n][r][ow] = sum over the outputs (oh, ow) whose column pass selected row r
 template <typename T>
-__global__ void maxpool_bwd_scatter_kernel(const T* __restrict__ dy, int N, int OH, int OW, int C, int lddy,
-                                           const uint8_t* __restrict__ amax, float* __restrict__ scratch, int H, int W,
-                                           int k, int stride, int pad) {
-    const long total = (long)N * OH * OW * C;
+__global__ void maxpool_bwd_cols_kernel(const T* __restrict__ dy, int N, int OH, int OW, int C, int lddy,
+                                        const uint8_t* __restrict__ a1, float* __restrict__ dm1, int H, int k, int stride,
+                                        int pad) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH;
+    const long total = (long)N * H * OW * cpr;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long p = i / C;
-        const int c = (int)(i - p * C);
-        const int ow = (int)(p % OW), oh = (int)((p / OW) % OH), n = (int)(p / ((long)OW * OH));
-        const int a = amax[i] / k, b = amax[i] % k;
-        const int h = oh * stride - pad + a, w = ow * stride - pad + b;
-        atomicAdd(scratch + ((long)(n * H + h) * W + w) * C + c, (float)dy[p * lddy + c]);
+        const long p = i / cpr;                       // (n, r, ow)
+        const int ck = (int)(i - p * cpr);
+        const int ow = (int)(p % OW), r = (int)((p / OW) % H), n = (int)(p / ((long)OW * H));
+        float acc[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+        for (int a = 0; a < k; ++a) {
+            const int t = r + pad - a;
+            if (t < 0 || t % stride) continue;
+            const int oh = t / stride;
+            if (oh >= OH) continue;
+            const long q = ((long)n * OH + oh) * OW + ow;
+            int sel[CH];
+            load_bytes<CH>(a1 + q * C + ck * CH, sel);
+            float f[CH];
+            chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(dy + q * lddy + ck * CH), f);
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+                if (sel[e] == a) acc[e] += f[e];
+        }
+        float* dst = dm1 + p * C + ck * CH;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) dst[e] = acc[e];
+    }
+}
+
+// backward pass 2: dx[n][r][w] (+)= sum over the (r, ow) whose row pass selected column w
+template <typename T>
+__global__ void maxpool_bwd_rows_kernel(const float* __restrict__ dm1, const uint8_t* __restrict__ b1, int N, int H, int OW,
+                                        int C, T* __restrict__ dx, int W, int lddx, int k, int stride, int pad,
+                                        int accumulate) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH;
+    const long total = (long)N * H * W * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / cpr;                       // (n, r, w)
+        const int ck = (int)(i - p * cpr);
+        const int w = (int)(p % W);
+        const long nr = p / W;                        // n * H + r
+        float acc[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+        for (int b = 0; b < k; ++b) {
+            const int t = w + pad - b;
+            if (t < 0 || t % stride) continue;
+            const int ow = t / stride;
+            if (ow >= OW) continue;
+            const long q = (nr * OW + ow) * C + ck * CH;
+            int sel[CH];
+            load_bytes<CH>(b1 + q, sel);
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+                if (sel[e] == b) acc[e] += dm1[q + e];
+        }
+        T* dst = dx + p * lddx + ck * CH;
+        if (accumulate) {
+            float old[CH];
+            chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(dst), old);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) acc[e] += old[e];
+        }
+        *reinterpret_cast<u32x4*>(dst) = f32_to_chunk<T>(acc);
     }
 }
 
@@ -625,15 +740,22 @@ extern "C" int cy_slice_add(const void* a, int lda, const void* b, int ldb, void
     return 0;
 }
 
+extern "C" int64_t cy_maxpool_argmax_bytes(int N, int H, int OH, int OW, int C) { return (int64_t)N * (OH + H) * OW * C; }
+
 extern "C" int cy_maxpool_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int OH, int OW, int ldy,
-                              int k, int stride, int pad, uint8_t* argmax, int dtype, cy_stream_t s) {
+                              int k, int stride, int pad, uint8_t* argmax, void* scratch, int dtype, cy_stream_t s) {
     CY_ENTER();
     const int ch = dtype == CY_F16 ? 8 : 4;
-    if (!x || !y || C % ch || ldx % ch || ldy % ch || k < 1 || k > 15) return CY_ERR_ARG;
-    const int g = grid_for((long)N * OH * OW * (C / ch));
-#define CY_MP(T) \
-    hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), (const T*)x, N, H, W, C, ldx, (T*)y, OH, \
-                       OW, ldy, k, stride, pad, argmax);
+    if (!x || !y || !scratch || C % ch || ldx % ch || ldy % ch || k < 1 || k > 15 || stride < 1) return CY_ERR_ARG;
+    uint8_t* a1 = argmax;
+    uint8_t* b1 = argmax ? argmax + (size_t)N * OH * OW * C : nullptr;
+    const int g1 = grid_for((long)N * H * OW * (C / ch));
+    const int g2 = grid_for((long)N * OH * OW * (C / ch));
+#define CY_MP(T)                                                                                                        \
+    hipLaunchKernelGGL((maxpool_rows_kernel<T>), dim3(g1), dim3(256), 0, cy_s(s), (const T*)x, N, H, W, C, ldx, (T*)scratch, \
+                       OW, k, stride, pad, b1);                                                                         \
+    hipLaunchKernelGGL((maxpool_cols_kernel<T>), dim3(g2), dim3(256), 0, cy_s(s), (const T*)scratch, N, H, C, (T*)y, OH,  \
+                       OW, ldy, k, stride, pad, a1);
     CY_DT_SWITCH(dtype, CY_MP(f16), CY_MP(float))
 #undef CY_MP
     CY_LAUNCH_CHECK();
@@ -644,16 +766,17 @@ extern "C" int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int 
                               int H, int W, int lddx, int k, int stride, int pad, int accumulate, float* scratch,
                               int dtype, cy_stream_t s) {
     CY_ENTER();
-    if (!dy || !argmax || !dx || !scratch) return CY_ERR_ARG;
-    const long in_elems = (long)N * H * W * C;
-    if (hipMemsetAsync(scratch, 0, in_elems * sizeof(float), cy_s(s)) != hipSuccess) return -(1000 + 1);
-    const int g = grid_for((long)N * OH * OW * C);
-    const int g2 = grid_for(in_elems);
-#define CY_MB(T)                                                                                                       \
-    hipLaunchKernelGGL((maxpool_bwd_scatter_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), (const T*)dy, N, OH, OW, C, lddy, \
-                       argmax, scratch, H, W, k, stride, pad);                                                         \
-    hipLaunchKernelGGL((f32_to_view_kernel<T>), dim3(g2), dim3(256), 0, cy_s(s), (const float*)scratch,                \
-                       (long)N * H * W, C, 1.f, (const float*)nullptr, (T*)dx, lddx, C, accumulate);
+    const int ch = dtype == CY_F16 ? 8 : 4;
+    if (!dy || !argmax || !dx || !scratch || C % ch || lddy % ch || lddx % ch || stride < 1) return CY_ERR_ARG;
+    const uint8_t* a1 = argmax;
+    const uint8_t* b1 = argmax + (size_t)N * OH * OW * C;
+    const int g1 = grid_for((long)N * H * OW * (C / ch));
+    const int g2 = grid_for((long)N * H * W * (C / ch));
+#define CY_MB(T)                                                                                                          \
+    hipLaunchKernelGGL((maxpool_bwd_cols_kernel<T>), dim3(g1), dim3(256), 0, cy_s(s), (const T*)dy, N, OH, OW, C, lddy, a1,  \
+                       scratch, H, k, stride, pad);                                                                       \
+    hipLaunchKernelGGL((maxpool_bwd_rows_kernel<T>), dim3(g2), dim3(256), 0, cy_s(s), (const float*)scratch, b1, N, H, OW, C, \
+                       (T*)dx, W, lddx, k, stride, pad, accumulate);
     CY_DT_SWITCH(dtype, CY_MB(f16), CY_MB(float))
 #undef CY_MB
     CY_LAUNCH_CHECK();

@@ -84,11 +84,13 @@ class Engine:
         self.argmax, self.pool_scratch = {}, None
         max_pool_in = 1
         for rec in plan.fwd:
-            if rec['op'] == 'pool' and training:
-                o = rec['out']
-                self.argmax[rec['idx']] = torch.empty(N * o.st.H * o.st.W * o.C, dtype=torch.uint8, device=device)
-                x = rec['x']
-                max_pool_in = max(max_pool_in, N * x.st.H * x.st.W * x.C)
+            if rec['op'] == 'pool':
+                o, x = rec['out'], rec['x']
+                if training:
+                    self.argmax[rec['idx']] = torch.empty(ops.maxpool_argmax_bytes(N, x.st.H, o.st.H, o.st.W, o.C),
+                                                          dtype=torch.uint8, device=device)
+                # row-pass intermediate N x H x OW x C (forward: tensor dtype, backward: fp32)
+                max_pool_in = max(max_pool_in, N * x.st.H * max(o.st.W, x.st.W) * x.C)
         self.pool_scratch = torch.empty(max_pool_in, **f32)
         # heads
         self.outputs = torch.empty(N, plan.rows_total, 7 + plan.heads[0]['C'], **f32) if plan.heads else None
@@ -216,7 +218,7 @@ class Engine:
 
     def _f_pool(self, rec, *_):
         ops.maxpool_fwd(self.view(rec['x']), self.view(rec['out']), rec['k'], rec['stride'], rec['pad'],
-                        self.argmax.get(rec['idx']))
+                        self.argmax.get(rec['idx']), self.pool_scratch)
 
     def _f_upsample(self, rec, *_):
         ops.upsample_fwd(self.view(rec['x']), self.view(rec['out']), rec['stride'])

@@ -334,9 +334,14 @@ def bn_act_bwd_apply(x, dy, dx, res_grad, res_accum, mean, invstd, scale, shift,
                _p(shift), _p(dgs), _p(dbs), act, x.dt, _stream())
 
 
-def maxpool_fwd(x, y, k, stride, pad, argmax):
-    lib().call('cy_maxpool_fwd', _p(x), x.N, x.H, x.W, x.C, x.ld, _p(y), y.H, y.W, y.ld, k, stride, pad, _p(argmax), x.dt,
-               _stream())
+def maxpool_argmax_bytes(N, H, OH, OW, C):
+    return int(lib().raw('cy_maxpool_argmax_bytes')(N, H, OH, OW, C))
+
+
+def maxpool_fwd(x, y, k, stride, pad, argmax, scratch):
+    """scratch: any device tensor with >= N*H*OW*C elements of x's dtype worth of bytes (row-pass maxima)."""
+    lib().call('cy_maxpool_fwd', _p(x), x.N, x.H, x.W, x.C, x.ld, _p(y), y.H, y.W, y.ld, k, stride, pad, _p(argmax),
+               _p(scratch), x.dt, _stream())
 
 
 def maxpool_bwd(dy, argmax, dx, k, stride, pad, accumulate, scratch):

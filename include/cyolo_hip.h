@@ -158,11 +158,15 @@ int cy_bn_act_bwd_apply(const void* x, int ldx, const void* dy, int lddy, void* 
                         int act, int dtype, cy_stream_t s);
 
 /* Data-movement blocks of Darknet.forward (darknet2pytorch.py:180-219, :64-79, :285). */
+/* Max pooling (SPP 5/9/13 stride 1, tiny's 2x2 stride 2) as a row pass and a column pass (k + k loads per output, torch's
+ * value and tie rule).  `scratch`: >= N*H*OW*C elements of the tensor dtype (forward) / floats (backward).  `argmax`
+ * (training; NULL in eval): cy_maxpool_argmax_bytes bytes holding the two passes' tap indices; the backward gathers
+ * through the same two stages (no atomics).  dx: stored or accumulated into. */
+int64_t cy_maxpool_argmax_bytes(int N, int H, int OH, int OW, int C);
 int cy_maxpool_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int OH, int OW, int ldy, int k,
-                   int stride, int pad, uint8_t* argmax, int dtype, cy_stream_t s);
+                   int stride, int pad, uint8_t* argmax, void* scratch, int dtype, cy_stream_t s);
 int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int lddy, const uint8_t* argmax, void* dx, int H,
-                   int W, int lddx, int k, int stride, int pad, int accumulate, float* scratch, int dtype,
-                   cy_stream_t s);
+                   int W, int lddx, int k, int stride, int pad, int accumulate, float* scratch, int dtype, cy_stream_t s);
 int cy_upsample_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, int stride, int dtype,
                     cy_stream_t s);
 int cy_upsample_bwd(const void* dy, int N, int H, int W, int C, int lddy, void* dx, int lddx, int stride,

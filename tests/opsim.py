@@ -195,7 +195,11 @@ def bn_act_bwd_apply(x, dy, dx, res_grad, res_accum, mean, invstd, scale, shift,
     _store(dx, out)
 
 
-def maxpool_fwd(x, y, k, stride, pad, argmax):
+def maxpool_argmax_bytes(N, H, OH, OW, C):
+    return N * (OH + H) * OW * C
+
+
+def maxpool_fwd(x, y, k, stride, pad, argmax, scratch=None):
     a = _nchw(x)
     N, C, H, W = a.shape
     yv, idx = F.max_pool2d(a, k, stride, pad, return_indices=True)
@@ -206,13 +210,13 @@ def maxpool_fwd(x, y, k, stride, pad, argmax):
         oh = torch.arange(OH).view(1, 1, OH, 1) * stride - pad
         ow = torch.arange(OW).view(1, 1, 1, OW) * stride - pad
         code = (ih - oh) * k + (iw - ow)
-        argmax.view(N, OH, OW, C).copy_(code.permute(0, 2, 3, 1).to(torch.uint8))
+        argmax[:N * OH * OW * C].view(N, OH, OW, C).copy_(code.permute(0, 2, 3, 1).to(torch.uint8))
 
 
 def maxpool_bwd(dy, argmax, dx, k, stride, pad, accumulate, scratch):
     g = _nchw(dy)
     N, C, OH, OW = g.shape
-    code = argmax.view(N, OH, OW, C).permute(0, 3, 1, 2).long()
+    code = argmax[:N * OH * OW * C].view(N, OH, OW, C).permute(0, 3, 1, 2).long()
     oh = torch.arange(OH).view(1, 1, OH, 1) * stride - pad
     ow = torch.arange(OW).view(1, 1, 1, OW) * stride - pad
     ih, iw = oh + code // k, ow + code % k
@@ -277,7 +281,7 @@ def yolo_loss(logits, B, G, A, C, targets, anchors, img_size, ignore_thresh, use
 NAMES = ['check_device_tensor', 'nchw_to_nhwc', 'pack_weights_into', 'make_pack_table', 'pack_weights_multi',
          'make_reduce_table', 'wgrad_reduce_multi', 'conv_bn_act_eval', 'conv_igemm', 'conv_wgrad', 'wgrad_reduce',
          'bn_finalize', 'bn_eval_affine', 'bn_act_fwd', 'bn_act_bwd_reduce', 'bn_bwd_finalize', 'bn_act_bwd_apply',
-         'maxpool_fwd', 'maxpool_bwd', 'upsample_fwd', 'upsample_bwd', 'slice_copy', 'slice_add', 'f32_to_view',
+         'maxpool_argmax_bytes', 'maxpool_fwd', 'maxpool_bwd', 'upsample_fwd', 'upsample_bwd', 'slice_copy', 'slice_add', 'f32_to_view',
          'zero_view', 'bias_grad', 'yolo_decode', 'yolo_loss']
 
 

@@ -274,12 +274,12 @@ def test_maxpool(dt, k, stride):
     y.backward(dy.double())
     xv = View.from_nchw(x.to(DEV), dt)
     yv = View.alloc(N, y.shape[2], y.shape[3], C, dt, ld=C + 16)
-    am = torch.zeros(N * y.shape[2] * y.shape[3] * C, dtype=torch.uint8, device=DEV)
-    ops.maxpool_fwd(xv, yv, k, stride, pad, am)
+    am = torch.zeros(ops.maxpool_argmax_bytes(N, H, y.shape[2], y.shape[3], C), dtype=torch.uint8, device=DEV)
+    scratch = torch.empty(N * H * W * C, device=DEV)
+    ops.maxpool_fwd(xv, yv, k, stride, pad, am, scratch)
     torch.testing.assert_close(yv.to_nchw().cpu(), y.detach().float(), rtol=0, atol=0)
     dyv = View.from_nchw(dy.to(DEV), dt)
     dxv = View.from_nchw(torch.ones(N, C, H, W).to(DEV), dt)
-    scratch = torch.empty(N * H * W * C, device=DEV)
     ops.maxpool_bwd(dyv, am, dxv, k, stride, pad, True, scratch)
     torch.testing.assert_close(dxv.to_nchw().cpu(), 1 + xr.grad.float(), **_tol(dt))
 
