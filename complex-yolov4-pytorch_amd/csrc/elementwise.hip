@@ -470,35 +470,80 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Co, int Ci,
     }
 }
 
-// Both packed layouts are written coalesced (the fp32 master is gathered instead: reads are absorbed by L2, scattered
-// 2-byte writes are not).  The block table enumerates elements of the forward layout; the dgrad layout has the same
-// element count, so the same block also writes "its" range of the dgrad matrix.
+// Table-driven pack of every conv's fp32 OIHW master into the two MFMA operand layouts.  One block = one 64 (co) x 64 (ci)
+// tile with all ks*ks taps: the master is read in contiguous runs (64 * ks*ks floats per output channel), transposed
+// through LDS, and both packed matrices are written in 64-element runs.  (The previous element-per-thread gather read
+// the master with a stride of ks*ks floats: rocprofv3 FETCH_SIZE showed 4.7 GB fetched for 256 MB of weights.)
+// blocks[2b + 1] = tile index * 4 (the generic table counts CY_MULTI_ELEMS "elements" per block).
+template <typename T, int KK>
+__device__ __forceinline__ void pack_tile(const cy_pack_desc& d, int tile, T* lds) {
+    constexpr int CH = Elem<T>::CH;          // elements per 16 bytes
+    const int kk = KK > 0 ? KK : d.ks * d.ks;   // KK = 9 / 1: compile-time taps (the divisions below become multiplies)
+    const int tiles_ci = (d.CiPad + 63) / 64;
+    const int co0 = (tile / tiles_ci) * 64, ci0 = (tile % tiles_ci) * 64;
+    const int ROW = kk * 64 + CH;            // elements; one 16-byte chunk of padding keeps rows aligned and staggers the banks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = 64 * kk;
+    const bool vec = ((d.Ci * kk) & 3) == 0 && ci0 + 64 <= d.Ci;   // whole 16-byte groups of the master row are valid
+    for (int r = wave; r < 64; r += 4) {
+        const int co = co0 + r;
+        const float* src = d.w + ((long)co * d.Ci + ci0) * kk;
+        if (vec && co < d.Co) {
+            for (int j4 = lane * 4; j4 < seg; j4 += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(src + j4);
+                const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = j4 + e, ci_l = j / kk, tap = j - ci_l * kk;
+                    lds[r * ROW + tap * 64 + ci_l] = (T)f[e];
+                }
+            }
+        } else {
+            for (int j = lane; j < seg; j += 64) {
+                const int ci_l = j / kk, tap = j - ci_l * kk;
+                const float v = (co < d.Co && ci0 + ci_l < d.Ci) ? src[j] : 0.f;
+                lds[r * ROW + tap * 64 + ci_l] = (T)v;
+            }
+        }
+    }
+    __syncthreads();
+    T* wf = (T*)d.wf;
+    T* wd = (T*)d.wd;
+    constexpr int CPT = 64 / CH;             // 16-byte chunks per 64-element run
+    const int nchunks = 64 * kk * CPT;
+    for (int idx = tid; idx < nchunks; idx += 256) {         // forward layout [co][tap][ci]: 16 bytes of ci per thread
+        const int cc = idx % CPT, t2 = idx / CPT;
+        const int r = t2 / kk, tap = t2 - r * kk;
+        const int co = co0 + r, ci = ci0 + cc * CH;
+        if (co < d.CoPad && ci < d.CiPad)    // CiPad is a multiple of CH
+            *reinterpret_cast<u32x4*>(wf + ((long)co * kk + tap) * d.CiPad + ci) =
+                *reinterpret_cast<const u32x4*>(lds + r * ROW + tap * 64 + cc * CH);
+    }
+    if (wd) {
+        for (int idx = tid; idx < nchunks; idx += 256) {     // dgrad layout [ci][tap][co]: 16 bytes of co per thread
+            const int cc = idx % CPT, t2 = idx / CPT;
+            const int ci_l = t2 / kk, tap = t2 - ci_l * kk;
+            const int co = co0 + cc * CH, ci = ci0 + ci_l;
+            if (co < d.CoPad && ci < d.CiPad) {
+                T v[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) v[e] = lds[(cc * CH + e) * ROW + tap * 64 + ci_l];
+                *reinterpret_cast<u32x4*>(wd + ((long)ci * kk + tap) * d.CoPad + co) = *reinterpret_cast<const u32x4*>(v);
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) pack_weights_multi_kernel(const cy_pack_desc* __restrict__ desc,
                                                                 const int* __restrict__ blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pk_smem[];
+    T* lds = reinterpret_cast<T*>(pk_smem);
     const cy_pack_desc d = desc[blocks[2 * blockIdx.x]];
-    const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
-    const int kk = d.ks * d.ks;
-    const long total = (long)d.CoPad * kk * d.CiPad;
-    T* wf = (T*)d.wf;
-    T* wd = (T*)d.wd;
-#pragma unroll
-    for (int it = 0; it < CY_MULTI_ELEMS / 256; ++it) {
-        const long i = first + it * 256 + threadIdx.x;
-        if (i >= total) break;
-        {   // forward layout [co][tap][ci]
-            const int ci = (int)(i % d.CiPad);
-            const int tap = (int)((i / d.CiPad) % kk);
-            const int co = (int)(i / ((long)d.CiPad * kk));
-            wf[i] = (T)((co < d.Co && ci < d.Ci) ? d.w[((long)co * d.Ci + ci) * kk + tap] : 0.f);
-        }
-        if (wd) {   // dgrad layout [ci][tap][co]
-            const int co = (int)(i % d.CoPad);
-            const int tap = (int)((i / d.CoPad) % kk);
-            const int ci = (int)(i / ((long)d.CoPad * kk));
-            wd[i] = (T)((co < d.Co && ci < d.Ci) ? d.w[((long)co * d.Ci + ci) * kk + tap] : 0.f);
-        }
-    }
+    const int tile = blocks[2 * blockIdx.x + 1] >> 2;
+    if (d.ks == 3) pack_tile<T, 9>(d, tile, lds);
+    else if (d.ks == 1) pack_tile<T, 1>(d, tile, lds);
+    else pack_tile<T, 0>(d, tile, lds);
 }
 
 struct AdamGroups {
@@ -854,10 +899,19 @@ extern "C" int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* bl
                                      cy_stream_t s) {
     CY_ENTER();
     if (!desc || !blocks || nblocks < 1) return CY_ERR_ARG;
+    // LDS for the largest tile (3x3 taps): 64 rows x (9 * 64 + one 16-byte chunk) elements (75 KB f16 / 148 KB f32)
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_weights_multi_kernel<f16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (9 * 64 + 8) * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_weights_multi_kernel<float>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (9 * 64 + 4) * 4);
+        attr_done = true;
+    }
     if (dtype == CY_F16)
-        hipLaunchKernelGGL((pack_weights_multi_kernel<f16>), dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks);
+        hipLaunchKernelGGL((pack_weights_multi_kernel<f16>), dim3(nblocks), dim3(256), 64 * (9 * 64 + 8) * 2, cy_s(s), desc, blocks);
     else if (dtype == CY_F32)
-        hipLaunchKernelGGL((pack_weights_multi_kernel<float>), dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks);
+        hipLaunchKernelGGL((pack_weights_multi_kernel<float>), dim3(nblocks), dim3(256), 64 * (9 * 64 + 4) * 4, cy_s(s), desc, blocks);
     else
         return CY_ERR_ARG;
     CY_LAUNCH_CHECK();

@@ -201,7 +201,8 @@ def make_pack_table(items, device):
     for w, wf, wd, cop, cip in items:
         Co, Ci, ks, _ = w.shape
         raw += struct.pack('<QQQiiiiii', w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else 0, Co, Ci, ks, cop, cip, 0)
-        counts.append(cop * ks * ks * cip)
+        assert ks <= 3
+        counts.append(((cop + 63) // 64) * ((cip + 63) // 64) * MULTI_ELEMS)   # one block per 64 x 64 (co, ci) tile
     desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     blocks = torch.tensor(_block_table(counts), dtype=torch.int32, device=device)
     return desc, blocks

@@ -48,7 +48,9 @@ int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad, int CiPad
 
 /* Table-driven variants: ONE launch for every conv of the network (the per-layer calls above cost a kernel boundary
  * each, ~110 per step).  `desc` is a device array of cy_pack_desc / cy_reduce_desc; `blocks` a device array of
- * (descriptor index, first element / 256) pairs, one per 256-thread block covering CY_MULTI_ELEMS elements. */
+ * (descriptor index, first element / 256) pairs, one per 256-thread block covering CY_MULTI_ELEMS elements; for the
+ * pack table an "element" run of CY_MULTI_ELEMS stands for one 64 x 64 (co, ci) tile of the padded weight matrix
+ * (tile = second entry / 4, tiles enumerated ci-fastest, ks <= 3). */
 typedef struct {
     const float* w; void* wf; void* wd;
     int Co, Ci, ks, CoPad, CiPad, pad_;
