@@ -5,11 +5,17 @@
 // ends up with 4 consecutive output channels of one pixel -> one packed NHWC store.
 //
 // Block = 256 threads = 4 waves (2 over channels x 2 over pixels); tile BN channels x BM pixels;
-// K step = one 128-byte LDS row per tile row (64 f16 / 32 f32).  Tiles are staged
-// global -> VGPR -> LDS (zero fill for padding / K tail / dgrad stride holes), double buffered, one
-// barrier per K step.  LDS rows are 128 B with the 16-byte chunk index XOR-swizzled by (row & 7):
-// conflict-free for the ds_read_b128 lane groups (see DESIGN.md section kernels).
+// K step = one 128-byte LDS row per tile row (64 f16 / 32 f32).  Tiles go global -> LDS by
+// buffer_load_dwordx4 ... lds in 1 KB pieces (an out-of-range offset = zero fill: padding, K tail,
+// dgrad stride holes), double buffered, one barrier per K step.  LDS rows are 128 B with the 16-byte
+// chunk index XOR-swizzled by (row & 7) -- applied on the source side, the DMA image being
+// lane-linear -- conflict-free for the ds_read_b128 lane groups (see DESIGN.md section kernels).
 // f16: v_mfma_f32_16x16x32_f16.  f32 (parity mode): v_mfma_f32_16x16x4_f32, exact f32.
+//
+// Two kernels share the scheme: igemm_fast_kernel (Cin a multiple of the K step: wave-uniform tap per
+// step, SGPR offsets) runs every layer but the first two; igemm_kernel (per-lane tap, any Cin, also
+// the register-staged and 3-stage / 512-thread experiment variants) runs the rest.  CY_IGEMM_* environment
+// variables select variants and timing experiments.
 #include <stdio.h>
 #include <stdlib.h>
 
