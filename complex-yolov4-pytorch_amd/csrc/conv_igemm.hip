@@ -456,7 +456,7 @@ int launch(const IgemmParams& p, hipStream_t s) {
 
 // Tile choice.  Channel tile = min(128, OC rounded up to 32).  Pixel tile: blocks run in rounds of 256 * blocks-per-CU
 // (LDS-limited) and a K step costs ~1 us per resident block almost independently of the tile area (the double-buffered
-// loop is latency-bound; tools/tile_sweep*.sh), so
+// loop is latency-bound; CY_IGEMM_TILE sweeps with tools/conv_micro.py), so
 //   * a problem that does not even fill one round of 128-pixel tiles uses 64-pixel tiles (more blocks in flight);
 //   * a problem that needs several rounds uses 192-pixel tiles when that saves a round (e.g. the 76x76 layers at
 //     batch 16: 722 tiles = 2 rounds at 128, 482 tiles = 1 round at 192; measured in-model 0.43 -> 0.375 ms).
