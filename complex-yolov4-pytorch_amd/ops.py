@@ -497,6 +497,8 @@ def bev_rasterize(points, bounds, disc, H, W, workspace, out=None, zshift=None, 
     check_device_tensor(points, 'points')
     pts = points.contiguous()
     assert pts.dtype == torch.float32 and pts.dim() == 2 and pts.shape[1] == 4
+    if pts.data_ptr() % 16:      # the kernel reads float4 points (a row slice of a larger tensor is only 4-byte aligned... 16 B per row keeps it aligned, a column offset does not)
+        pts = pts.clone()
     if out is None:
         out = torch.empty(3, H, W, dtype=torch.float32, device=pts.device)
     zshift = bounds[4] if zshift is None else zshift
