@@ -311,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
         bn[k] = n; boh[k] = rem / p.OW; bow[k] = rem - boh[k] * p.OW;
     }
     const unsigned pixb = (unsigned)p.ldx * 2u;
+    const int adv_h = BKP / p.OW, adv_w = BKP - adv_h * p.OW;
 
     auto load_tile = [&](int kt, int stage) {
         unsigned char* as_w = smem + stage * STAGE + wave_u * 1024;
@@ -328,9 +329,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
             const bool ok = b_cok[k] & (m < pix_end) & ((unsigned)xh < (unsigned)p.XH) & ((unsigned)xw < (unsigned)p.XW);
             const unsigned v = ok ? (unsigned)((bn[k] * p.XH + xh) * p.XW + xw) * pixb + b_ci[k] : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(bs_w + k * 4096), 16, v, 0, 0, 0);
-            bow[k] += BKP;
-            while (bow[k] >= p.OW) { bow[k] -= p.OW; ++boh[k]; }
-            while (boh[k] >= p.OH) { boh[k] -= p.OH; ++bn[k]; }
+            // advance the row's pixel by BKP = adv_h * OW + adv_w without loops (the host guarantees adv_h + 1 <= 2 * OH)
+            bow[k] += adv_w;
+            const bool cw = bow[k] >= p.OW;
+            bow[k] -= cw ? p.OW : 0;
+            boh[k] += adv_h + (cw ? 1 : 0);
+            const bool c1 = boh[k] >= p.OH;
+            boh[k] -= c1 ? p.OH : 0;
+            const bool c2 = boh[k] >= p.OH;
+            boh[k] -= c2 ? p.OH : 0;
+            bn[k] += (c1 ? 1 : 0) + (c2 ? 1 : 0);
         }
     };
 
@@ -582,7 +590,7 @@ extern "C" int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int 
     {   // direct-to-LDS kernel (CY_WGRAD_DMA=0: register-staged kernel, A/B runs; use_tr = 2 forces the staged kernel too)
         const char* e = getenv("CY_WGRAD_DMA");
         const size_t xb = (((size_t)N * XH * XW - 1) * ldx + Ci) * 2, ab = ((size_t)p.M + 128) * lddy * 2;
-        if (use_tr == 1 && !(e && !atoi(e)) && xb < 0xFFFFFF00ull && ab < 0xFFFFFF00ull) {
+        if (use_tr == 1 && !(e && !atoi(e)) && xb < 0xFFFFFF00ull && ab < 0xFFFFFF00ull && 64 / OW + 1 <= 2 * OH) {
             p.x_bytes = (unsigned)xb;
             return dispatch_dma(p, split, cy_s(s));
         }
