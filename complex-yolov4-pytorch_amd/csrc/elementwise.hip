@@ -551,7 +551,8 @@ struct AdamGroups {
 };
 __global__ void __launch_bounds__(256) adam_multi_kernel(const cy_adam_desc* __restrict__ desc, const int* __restrict__ blocks,
                                                         float beta1, float beta2, float eps, float bc1, float bc2,
-                                                        int zero_grad, AdamGroups grp) {
+                                                        int zero_grad, AdamGroups grp, const int* __restrict__ skip) {
+    if (skip && *skip) return;   // a non-finite gradient was found (cy_grad_nonfinite): the step is skipped as a whole
     const cy_adam_desc d = desc[blocks[2 * blockIdx.x]];
     const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
     const float lr = grp.lr[d.group & 7], wdecay = grp.wd[d.group & 7];
@@ -575,7 +576,8 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const cy_adam_desc* __r
 // torch.optim.SGD (dampening 0): g += wd * p;  buf = first step ? g : momentum * buf + g;  p -= lr * (nesterov ? g + momentum * buf : buf)
 __global__ void __launch_bounds__(256) sgd_multi_kernel(const cy_adam_desc* __restrict__ desc, const int* __restrict__ blocks,
                                                        float momentum, int nesterov, int first_step, int zero_grad,
-                                                       AdamGroups grp) {
+                                                       AdamGroups grp, const int* __restrict__ skip) {
+    if (skip && *skip) return;
     const cy_adam_desc d = desc[blocks[2 * blockIdx.x]];
     const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
     const float lr = grp.lr[d.group & 7], wdecay = grp.wd[d.group & 7];
@@ -595,6 +597,20 @@ __global__ void __launch_bounds__(256) sgd_multi_kernel(const cy_adam_desc* __re
         d.p[i] = p - lr * upd;
         if (zero_grad) d.g[i] = 0.f;
     }
+}
+
+// flag = 1 when any gradient element is inf / nan (dynamic loss scaling: such a step must not reach the optimizer)
+__global__ void __launch_bounds__(256) grad_nonfinite_kernel(const float4* __restrict__ g, long n4, const float* __restrict__ tail,
+                                                            int ntail, int* __restrict__ flag) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = g[i];
+        // exponent all ones <=> inf or nan; OR of the four words' tests
+        bad |= ((__float_as_uint(v.x) & 0x7F800000u) == 0x7F800000u) | ((__float_as_uint(v.y) & 0x7F800000u) == 0x7F800000u) |
+               ((__float_as_uint(v.z) & 0x7F800000u) == 0x7F800000u) | ((__float_as_uint(v.w) & 0x7F800000u) == 0x7F800000u);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) bad |= (__float_as_uint(tail[threadIdx.x]) & 0x7F800000u) == 0x7F800000u;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 __global__ void bias_grad_kernel(const float* __restrict__ d, long M, int C, float scale,
@@ -920,7 +936,7 @@ extern "C" int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* bl
 
 extern "C" int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2,
                              float eps, float bias_corr1, float bias_corr2, int zero_grad, const float* group_lr_host,
-                             const float* group_wd_host, int ngroups, cy_stream_t s) {
+                             const float* group_wd_host, int ngroups, const int32_t* skip_flag, cy_stream_t s) {
     CY_ENTER();
     if (!desc || !blocks || nblocks < 1 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return CY_ERR_ARG;
     if (!group_lr_host || !group_wd_host || ngroups < 1 || ngroups > 8) return CY_ERR_ARG;
@@ -930,14 +946,14 @@ extern "C" int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, in
         grp.wd[i] = i < ngroups ? group_wd_host[i] : 0.f;
     }
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, beta1, beta2, eps, bias_corr1,
-                       bias_corr2, zero_grad, grp);
+                       bias_corr2, zero_grad, grp, (const int*)skip_flag);
     CY_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int cy_sgd_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float momentum, int nesterov,
                             int first_step, int zero_grad, const float* group_lr_host, const float* group_wd_host, int ngroups,
-                            cy_stream_t s) {
+                            const int32_t* skip_flag, cy_stream_t s) {
     CY_ENTER();
     if (!desc || !blocks || nblocks < 1 || momentum < 0.f) return CY_ERR_ARG;
     if (!group_lr_host || !group_wd_host || ngroups < 1 || ngroups > 8) return CY_ERR_ARG;
@@ -947,7 +963,19 @@ extern "C" int cy_sgd_multi(const cy_adam_desc* desc, const int32_t* blocks, int
         grp.wd[i] = i < ngroups ? group_wd_host[i] : 0.f;
     }
     hipLaunchKernelGGL(sgd_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, momentum, nesterov, first_step,
-                       zero_grad, grp);
+                       zero_grad, grp, (const int*)skip_flag);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_grad_nonfinite(const float* g, int64_t n, int32_t* flag, cy_stream_t s) {
+    CY_ENTER();
+    if (!g || !flag || n < 0 || ((uintptr_t)g & 15)) return CY_ERR_ARG;
+    if (hipMemsetAsync(flag, 0, sizeof(int32_t), cy_s(s)) != hipSuccess) return -(1000 + 1);
+    const long n4 = n / 4;
+    const int ntail = (int)(n - n4 * 4);
+    hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(256), 0, cy_s(s),
+                       reinterpret_cast<const float4*>(g), n4, g + n4 * 4, ntail, (int*)flag);
     CY_LAUNCH_CHECK();
     return 0;
 }

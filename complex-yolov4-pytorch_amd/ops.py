@@ -240,14 +240,19 @@ def make_adam_table(items, device):
     return desc, blocks
 
 
-def sgd_multi(desc, blocks, momentum, nesterov, first_step, lrs, wds, zero_grad=False):
+def sgd_multi(desc, blocks, momentum, nesterov, first_step, lrs, wds, zero_grad=False, skip_flag=None):
     lib().call('cy_sgd_multi', _p(desc), _p(blocks), blocks.shape[0], float(momentum), int(nesterov), int(first_step),
-               int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _stream())
+               int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _p(skip_flag), _stream())
 
 
-def adam_multi(desc, blocks, beta1, beta2, eps, bc1, bc2, lrs, wds, zero_grad=False):
+def grad_nonfinite(flat_grad, flag):
+    """flag (int32 device tensor [1]) <- 1 if flat_grad holds an inf / nan, else 0."""
+    lib().call('cy_grad_nonfinite', _p(flat_grad), flat_grad.numel(), _p(flag), _stream())
+
+
+def adam_multi(desc, blocks, beta1, beta2, eps, bc1, bc2, lrs, wds, zero_grad=False, skip_flag=None):
     lib().call('cy_adam_multi', _p(desc), _p(blocks), blocks.shape[0], float(beta1), float(beta2), float(eps), float(bc1),
-               float(bc2), int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _stream())
+               float(bc2), int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _p(skip_flag), _stream())
 
 
 def nchw_to_nhwc(x, cpad, dt, out=None):

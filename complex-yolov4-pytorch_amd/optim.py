@@ -48,7 +48,8 @@ class FusedAdam(torch.optim.Optimizer):
         assert len(self.param_groups) <= 8
         ops.adam_multi(self._table[0], self._table[1], b1, b2, self.param_groups[0]['eps'], 1 - b1 ** self._steps,
                        1 - b2 ** self._steps, [g['lr'] for g in self.param_groups],
-                       [g['weight_decay'] for g in self.param_groups], zero_grad=zero_grad)
+                       [g['weight_decay'] for g in self.param_groups], zero_grad=zero_grad,
+                       skip_flag=getattr(self, 'skip_flag', None))
         return loss
 
 
@@ -93,5 +94,64 @@ class FusedSGD(torch.optim.Optimizer):
         first = self._steps == 0 or fresh
         self._steps += 1
         ops.sgd_multi(self._table[0], self._table[1], g0['momentum'], g0['nesterov'], first,
-                      [g['lr'] for g in self.param_groups], [g['weight_decay'] for g in self.param_groups], zero_grad=zero_grad)
+                      [g['lr'] for g in self.param_groups], [g['weight_decay'] for g in self.param_groups], zero_grad=zero_grad,
+                      skip_flag=getattr(self, 'skip_flag', None))
         return loss
+
+
+class DynamicLossScale:
+    """Dynamic loss scaling for the fp16 backward (the role torch.cuda.amp.GradScaler plays for autocast models).
+
+    ``Darknet.loss_scale`` multiplies d(logits) before the half-precision backward pass and is divided out again in the
+    fp32 parameter-gradient reductions, so only the fp16 activation gradients see it.  Per step:
+
+        loss.backward();  scaler.check();  optimizer.step();  scaler.update()
+
+    ``check`` runs cy_grad_nonfinite over the model's flat gradient; the fused optimizers read the resulting device flag
+    and skip the whole step when it is set -- no host synchronisation on the step path.  ``update`` starts an
+    asynchronous copy of the flag and acts on the copy started one step earlier: after an overflow the scale is multiplied by
+    ``backoff_factor``, after ``growth_interval`` clean steps by ``growth_factor`` (one step late, which only delays
+    the adjustment)."""
+
+    def __init__(self, model, optimizer, init_scale=1.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                 max_scale=65536.0):
+        self.model = model.module if hasattr(model, 'module') else model
+        self.optimizer = optimizer
+        self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
+        self.growth_interval, self.max_scale = int(growth_interval), float(max_scale)
+        self.model.loss_scale = float(init_scale)
+        self._flag = self._host = self._event = None
+        self._clean = 0
+        self.skipped = 0
+
+    @property
+    def scale(self):
+        return self.model.loss_scale
+
+    def check(self):
+        flat = self.model.flat_grad
+        if flat is None:
+            return
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=flat.device)
+            self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.optimizer.skip_flag = self._flag
+        ops.grad_nonfinite(flat, self._flag)
+
+    def update(self):
+        if self._flag is None:
+            return
+        if self._event is not None:               # result of the PREVIOUS step's check
+            self._event.synchronize()
+            if int(self._host[0]):
+                self.model.loss_scale = max(self.model.loss_scale * self.backoff_factor, 2.0 ** -14)
+                self._clean = 0
+                self.skipped += 1
+            else:
+                self._clean += 1
+                if self._clean >= self.growth_interval:
+                    self.model.loss_scale = min(self.model.loss_scale * self.growth_factor, self.max_scale)
+                    self._clean = 0
+        self._host.copy_(self._flag, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()

@@ -75,12 +75,17 @@ typedef struct {
 } cy_adam_desc;
 int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2, float eps,
                   float bias_corr1, float bias_corr2, int zero_grad, const float* group_lr_host,
-                  const float* group_wd_host, int ngroups, cy_stream_t s);
+                  const float* group_wd_host, int ngroups, const int32_t* skip_flag, cy_stream_t s);
 /* Fused multi-tensor SGD with momentum / Nesterov (torch.optim.SGD semantics, dampening 0): the reference's other
  * optimizer choice (src/utils/train_utils.py:35-37: SGD(lr, momentum, nesterov=True)).  Uses cy_adam_desc with `m` as the
  * momentum buffer (`v` unused, may be NULL); first_step != 0 initialises the buffer with the gradient as torch does. */
 int cy_sgd_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float momentum, int nesterov, int first_step,
-                 int zero_grad, const float* group_lr_host, const float* group_wd_host, int ngroups, cy_stream_t s);
+                 int zero_grad, const float* group_lr_host, const float* group_wd_host, int ngroups, const int32_t* skip_flag,
+                 cy_stream_t s);
+/* Dynamic loss scaling (the fp16 counterpart of torch.cuda.amp.GradScaler; the reference trains in fp32 and needs none):
+ * *flag = 1 when any of the n fp32 gradient elements (16-byte aligned) is inf or nan, else 0.  The optimizer entry points
+ * above skip the whole step when their skip_flag (device pointer, may be NULL) is non-zero -- no host round trip. */
+int cy_grad_nonfinite(const float* g, int64_t n, int32_t* flag, cy_stream_t s);
 
 
 /* NCHW fp32 image batch [N][C][H][W] -> NHWC `dtype` view with CPad channels (extra channels zero).

@@ -175,3 +175,45 @@ def test_inference_and_nms_pipeline():
     assert len(dets) == 2
     for d in dets:
         assert d is None or (d.shape[1] == 9 and not d.is_cuda)
+
+
+def test_dynamic_loss_scale_backs_off_and_trains():
+    """fp16 mini net with DynamicLossScale started at an absurd scale: the overflowing steps are skipped on the device
+    (parameters untouched), the scale backs off until gradients are finite, then steps go through; the gradient of a
+    clean scaled step equals the unscaled one (the scale is divided out in the fp32 reductions)."""
+    from complex_yolov4_pytorch_amd.optim import DynamicLossScale, FusedAdam
+    from tests.util import mini_cfg_path
+    torch.manual_seed(0)
+    model = Darknet(mini_cfg_path(), use_giou_loss=True, dtype='f16')
+    sd = model.state_dict()
+    sd.update({k: syn.fill_tensor(k, tuple(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point})
+    model.load_state_dict(sd)
+    model.to(DEV).train()
+    x, tg = syn.bev_images(2, 64, seed=4, sparsity=0.5).to(DEV), syn.targets(2, 3, 64, seed=4).to(DEV)
+    loss, _ = model(x, tg)
+    loss.backward()
+    g_ref = model.flat_grad.clone()
+    opt = FusedAdam(model.parameters(), lr=1e-4)
+    scaler = DynamicLossScale(model, opt, init_scale=2.0 ** 40, backoff_factor=0.5 ** 8, growth_interval=1000)
+    p0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    scales, moved = [], []
+    for step in range(10):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model(x, tg)
+        loss.backward()
+        scaler.check()
+        opt.step()
+        scaler.update()
+        scales.append(scaler.scale)
+        moved.append(not torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), p0))
+    assert scaler.skipped >= 1 and scales[-1] < 2.0 ** 40          # it overflowed and backed off ...
+    assert not moved[0] and moved[-1]                                # ... the first step was skipped, later ones were taken
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    # a clean step at the final scale reproduces the unscaled gradient (fp16 rounding of the scaled activations aside)
+    model2 = Darknet(mini_cfg_path(), use_giou_loss=True, dtype='f16', loss_scale=256.0)
+    model2.load_state_dict(sd)
+    model2.to(DEV).train()
+    loss2, _ = model2(x, tg)
+    loss2.backward()
+    rel = float((model2.flat_grad - g_ref).norm() / g_ref.norm())
+    assert rel < 0.2, rel

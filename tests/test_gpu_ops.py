@@ -384,6 +384,35 @@ def test_fused_adam_matches_torch_adam():
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
 
 
+def test_nonfinite_gradient_skips_the_fused_step():
+    """cy_grad_nonfinite + the optimizers' device-side skip flag (dynamic loss scaling without a host round trip)."""
+    from complex_yolov4_pytorch_amd.optim import FusedAdam, FusedSGD
+    for n in (1000, 1003, 4):
+        g = _rand(n, seed=5).to(DEV)
+        flag = torch.ones(1, dtype=torch.int32, device=DEV)
+        ops.grad_nonfinite(g, flag)
+        assert int(flag) == 0
+        for bad in (float('inf'), float('-inf'), float('nan')):
+            g2 = g.clone(); g2[n - 1] = bad
+            ops.grad_nonfinite(g2, flag)
+            assert int(flag) == 1
+    for cls, kw in ((FusedAdam, {}), (FusedSGD, dict(momentum=0.9, nesterov=True))):
+        p = _rand(64, 32, seed=6).to(DEV).requires_grad_(True)
+        before = p.detach().clone()
+        opt = cls([p], lr=1e-2, **kw)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        opt.skip_flag = flag
+        p.grad = _rand(64, 32, seed=7).to(DEV)
+        p.grad[3, 3] = float('inf')
+        ops.grad_nonfinite(p.grad, flag)
+        opt.step()
+        torch.testing.assert_close(p.detach(), before, rtol=0, atol=0)      # skipped as a whole
+        p.grad[3, 3] = 0.5
+        ops.grad_nonfinite(p.grad, flag)
+        opt.step()
+        assert not torch.equal(p.detach(), before)
+
+
 @pytest.mark.parametrize('nesterov', [True, False])
 def test_fused_sgd_matches_torch_sgd(nesterov):
     """cy_sgd_multi vs torch.optim.SGD(momentum, nesterov) with the reference's three parameter groups, 5 steps."""
