@@ -183,7 +183,8 @@ def main():
             peak = MFMA_PEAK_TFLOPS[a.dtype]
             roofline = dict(bound='mfma', kernel='igemm_kernel (implicit-GEMM conv: forward + dgrad launches, all tile variants)',
                             achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                            traffic=pmc_traffic('igemm', a),
+                            traffic=(pmc_traffic('igemm', a) or {}).get('bytes_per_launch'),
+                            traffic_detail=pmc_traffic('igemm', a),
                             launches_per_step=ig['launches'] // 2, avg_launch_us=round(1e3 * ig['ms'] / ig['launches'], 2),
                             hbm_gbs_algorithmic=round(ig['bytes'] / (ig['ms'] * 1e-3) / 1e9, 1),
                             algorithmic_bytes_per_launch=round(ig['bytes'] / ig['launches']),
