@@ -187,7 +187,7 @@ int cy_slice_add(const void* a, int lda, const void* b, int ldb, void* y, int ld
 /* fp32 rows [M][C] (ld = C) -> `dtype` view with CPad channels, scaled; used for d(logits) -> head conv backward */
 int cy_f32_to_view(const float* x, int64_t M, int C, float scale, const float* scale_dev, void* y, int ldy, int CPad,
                    int dtype, cy_stream_t s);
-/* bias gradient of a head conv: gbias[c] += scale * sum_p dlogits[p][c].
+/* bias gradient of a head conv (C <= 32): gbias[c] += scale * sum_p dlogits[p][c].
  * In both calls the effective factor is scale * (*scale_dev) when scale_dev is non-NULL (the upstream
  * d(loss) scalar stays on the device: no host synchronisation in backward). */
 int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, const float* scale_dev, float* gbias,
