@@ -31,6 +31,7 @@ from complex_yolov4_pytorch_amd.utils.train_utils import create_optimizer  # noq
 CFG = os.path.join(ROOT, 'complex-yolov4-pytorch_amd', 'config', 'cfg', 'complex_yolov4.cfg')
 MFMA_PEAK_TFLOPS = {'f16': 2500.0, 'f32': 157.3}     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+HBM_PEAK_BPS = HBM_PEAK_GBS * 1e9
 
 
 class _OptCfg:
@@ -172,6 +173,25 @@ def main():
         for _ in range(2):
             step()
         summ = ops.PROFILER.summary() if rank == 0 else {}
+        by_bound = None
+        if rank == 0:
+            # the same launches split by which roof bounds them: arithmetic intensity above / below the ridge point
+            over = ops.PROFILER.bracket_overhead_ms()
+            ridge = MFMA_PEAK_TFLOPS[a.dtype] * 1e12 / HBM_PEAK_BPS
+            acc = {'mfma': [0.0, 0.0, 0.0, 0], 'hbm': [0.0, 0.0, 0.0, 0]}
+            for kind, fl, nb, ev0, ev1 in ops.PROFILER.records:
+                if kind != 'igemm' or nb <= 0:
+                    continue
+                k = 'mfma' if fl / nb >= ridge else 'hbm'
+                t = max(ev0.elapsed_time(ev1) - over, 1e-6)
+                acc[k][0] += fl; acc[k][1] += nb; acc[k][2] += t; acc[k][3] += 1
+            by_bound = {}
+            for k, (fl, nb, ms, n) in acc.items():
+                if n:
+                    by_bound[k] = dict(launches_per_step=n // 2, ms_per_step=round(ms / 2, 3),
+                                       tflops=round(fl / (ms * 1e-3) / 1e12, 1), gbs_algorithmic=round(nb / (ms * 1e-3) / 1e9, 1),
+                                       frac=round((fl / (ms * 1e-3)) / (MFMA_PEAK_TFLOPS[a.dtype] * 1e12), 4) if k == 'mfma'
+                                       else round((nb / (ms * 1e-3)) / HBM_PEAK_BPS, 4))
         ops.PROFILER = None
         for e, sd in sides:
             e.side = sd
@@ -196,6 +216,7 @@ def main():
                                                 launches_per_step=wg['launches'] // 2,
                                                 avg_launch_us=round(1e3 * wg['ms'] / wg['launches'], 2))
             roofline['conv_ms_per_step'] = round((ig['ms'] + (wg['ms'] if wg else 0)) / 2, 3)
+            roofline['by_bound'] = by_bound   # launches above the ridge point against the MFMA peak, the rest against HBM
     if world > 1:
         dist.barrier()
 
