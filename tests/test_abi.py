@@ -19,7 +19,7 @@ def built():
 
 def test_header_symbols_are_exported(built):
     protos = _lib.parse_header()
-    assert len(protos) >= 35
+    assert len(protos) >= 46
     dll = ctypes.CDLL(built)
     missing = [n for n in protos if not hasattr(dll, n)]
     assert not missing, missing
@@ -44,6 +44,15 @@ def test_argument_validation_without_launch(built):
     assert lib.raw('cy_conv_igemm')(None, 1, 8, 8, 8, 8, None, 8, None, 8, 8, 8, 8, 3, 1, 1, 0, 0, None, None, None, None) == -1
     assert lib.raw('cy_riou_pairs')(None, None, 4, 1, None, None, None, None) == -1
     assert lib.raw('cy_bn_act_fwd')(None, 8, None, 8, None, 0, 10, 8, None, None, 0, 0, None) == -1
+    # the entry points added around the path (rasteriser, pools, optimizers, loss scaling)
+    assert lib.raw('cy_bev_rasterize')(None, 10, 0., 50., -25., 25., -2.73, 1.27, -2.73, 4.0, 0.08, 608, 608, None, None, None) == -1
+    assert lib.raw('cy_maxpool_fwd')(None, 1, 8, 8, 8, 8, None, 8, 8, 8, 5, 1, 2, None, None, 0, None) == -1
+    assert lib.raw('cy_maxpool_argmax_bytes')(2, 19, 19, 19, 512) == 2 * (19 + 19) * 19 * 512
+    assert lib.raw('cy_grad_nonfinite')(None, 10, None, None) == -1
+    assert lib.raw('cy_sgd_multi')(None, None, 0, 0.9, 1, 1, 0, None, None, 0, None, None) == -1
+    assert lib.raw('cy_adam_multi')(None, None, 0, 0.9, 0.999, 1e-8, 0.1, 0.001, 0, None, None, 0, None, None) == -1
+    assert lib.raw('cy_bev_workspace')(608, 608) == 608 * 608 * 12
+    assert lib.raw('cy_halo_launches')() >= 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-device behaviour')
