@@ -265,7 +265,16 @@ __global__ void __launch_bounds__(256, 2) igemm_fast_kernel(const IgemmParams p)
     unsigned xoff[XR];
     int ximask[XR];
     const int ohw = p.OHc * p.OWc;
-    {
+    if (p.ks == 1 && p.stride == 1 && p.pad == 0 && ohw == p.OH * p.OW && (p.oh_mul | p.ow_mul) == 1) {
+        // 1x1 / stride 1: the source pixel IS the output pixel -- no divisions, no LDS hand-over, no barriers
+        const unsigned lane_const = (unsigned)p.x_bias + (unsigned)(chunk * CH) * (unsigned)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int m = tm * BM + rbase + RS * i;
+            xoff[i] = (unsigned)m * (unsigned)p.ldg * (unsigned)sizeof(T) + lane_const;
+            ximask[i] = m < p.M ? ~1 : ~0;
+        }
+    } else {
         uint2* rowinfo = reinterpret_cast<uint2*>(smem);
         if (tid < BM) {
             const int m = tm * BM + tid;
