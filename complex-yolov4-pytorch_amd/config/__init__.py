@@ -1,0 +1,1 @@
+"""Darknet cfg files (cfg/) and the KITTI BEV geometry constants."""

@@ -1,0 +1,1 @@
+"""LiDAR -> BEV rasterisation on the device (kitti_bev_utils)."""

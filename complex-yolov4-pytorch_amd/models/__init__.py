@@ -1,0 +1,1 @@
+"""Darknet cfg lowering (graph), executor (engine) and the reference-compatible model classes."""

@@ -1,40 +1,45 @@
-"""create_model / get_num_parameters / make_data_parallel -- drop-ins for reference src/models/model_utils.py.
-``make_data_parallel`` swaps torch DDP for the RCCL flat-buffer wrapper in ``parallel.py``."""
+"""create_model / get_num_parameters / make_data_parallel -- drop-ins for reference src/models/model_utils.py
+(:20-28, :31-38, :41-67): same names, same ``configs`` attributes read, same in-place edits of ``configs``.
+``make_data_parallel`` hands the model to the RCCL flat-buffer wrapper of ``parallel.py`` instead of torch DDP
+(SURVEY section 8a row K)."""
 import torch
 
 from .darknet2pytorch import Darknet
 
 
 def create_model(configs):
-    """reference model_utils.py:20-28"""
-    if (configs.arch == 'darknet') and (configs.cfgfile is not None):
-        print('using darknet')
-        model = Darknet(cfgfile=configs.cfgfile, use_giou_loss=configs.use_giou_loss,
-                        dtype=getattr(configs, 'dtype', 'f16'))
-    else:
-        assert False, 'Undefined model backbone'
-    return model
+    """Darknet built from ``configs.cfgfile``; ``configs.dtype`` ('f16' default / 'f32') picks the compute mode."""
+    if configs.arch != 'darknet' or configs.cfgfile is None:
+        raise AssertionError('Undefined model backbone')       # the reference asserts False here
+    print('using darknet')
+    return Darknet(cfgfile=configs.cfgfile, use_giou_loss=configs.use_giou_loss, dtype=getattr(configs, 'dtype', 'f16'))
 
 
 def get_num_parameters(model):
-    """reference model_utils.py:31-38"""
-    m = model.module if hasattr(model, 'module') else model
-    return sum(p.numel() for p in m.parameters() if p.requires_grad)
+    """Number of trainable scalars (of the wrapped module when the model is wrapped)."""
+    net = getattr(model, 'module', model)
+    return sum(w.numel() for w in net.parameters() if w.requires_grad)
+
+
+def _per_process(value, parts):
+    return int((value + parts - 1) / parts)
 
 
 def make_data_parallel(model, configs):
-    """reference model_utils.py:41-67.  One process per GPU; ``nn.DataParallel`` (the reference's last branch)
-    is refused: it scatters target rows across devices and breaks the sample-index column (App. A #20)."""
+    """One process per GPU.  Distributed: move the model to ``configs.gpu_idx``, split ``batch_size`` / ``num_workers``
+    over the node's GPUs as the reference does and wrap the model; single GPU: just move it.  The reference's last
+    branch (``nn.DataParallel`` over all visible GPUs) is refused: it scatters the rows of ``targets`` across devices and
+    breaks their sample-index column."""
     from ..parallel import RcclDataParallel
-    if configs.distributed:
-        if configs.gpu_idx is None:
-            raise ValueError('distributed training uses one process per GPU: pass --gpu_idx / launch with torchrun')
-        torch.cuda.set_device(configs.gpu_idx)
-        model.cuda(configs.gpu_idx)
-        configs.batch_size = int(configs.batch_size / configs.ngpus_per_node)
-        configs.num_workers = int((configs.num_workers + configs.ngpus_per_node - 1) / configs.ngpus_per_node)
-        return RcclDataParallel(model)
-    if configs.gpu_idx is not None:
-        torch.cuda.set_device(configs.gpu_idx)
-        return model.cuda(configs.gpu_idx)
-    raise ValueError('nn.DataParallel is not supported (it corrupts the targets tensor); pass --gpu_idx')
+    device = configs.gpu_idx
+    if device is None:
+        raise ValueError('nn.DataParallel is not supported (it corrupts the targets tensor); pass --gpu_idx '
+                         '(distributed runs: one process per GPU, e.g. torchrun)')
+    torch.cuda.set_device(device)
+    model = model.cuda(device)
+    if not configs.distributed:
+        return model
+    n = configs.ngpus_per_node
+    configs.batch_size = int(configs.batch_size / n)
+    configs.num_workers = _per_process(configs.num_workers, n)
+    return RcclDataParallel(model)

@@ -1,0 +1,1 @@
+"""Host-side mirrors of the reference utils: evaluation (NMS, mAP), rotated IoU, training helpers."""

@@ -8,32 +8,26 @@ from ..parallel import reduce_tensor, subdivisions_for  # noqa: F401
 
 
 def create_optimizer(configs, model):
-    """Same three parameter groups as reference train_utils.py:21-50 (biases / conv weights with decay / rest)."""
-    m = model.module if hasattr(model, 'module') else model
-    pg0, pg1, pg2 = [], [], []
-    for k, v in m.named_parameters():
-        if '.bias' in k:
-            pg2.append(v)
-        elif 'conv' in k and '.weight' in k:
-            pg1.append(v)
-        else:
-            pg0.append(v)
-    if configs.optimizer_type == 'sgd':
-        if getattr(configs, 'fused_optimizer', True) and pg0 and pg0[0].is_cuda:
-            from ..optim import FusedSGD
-            opt = FusedSGD(pg0, lr=configs.lr, momentum=configs.momentum, nesterov=True)
-        else:
-            opt = torch.optim.SGD(pg0, lr=configs.lr, momentum=configs.momentum, nesterov=True)
-    elif configs.optimizer_type == 'adam':
-        if getattr(configs, 'fused_optimizer', True) and pg0 and pg0[0].is_cuda:
-            from ..optim import FusedAdam
-            opt = FusedAdam(pg0, lr=configs.lr)
-        else:
-            opt = torch.optim.Adam(pg0, lr=configs.lr)
+    """The reference's three parameter groups (train_utils.py:21-50): everything that is neither a bias nor a conv weight
+    first (BatchNorm scales), then conv weights with ``configs.weight_decay``, then biases -- on the device the fused
+    multi-tensor optimizers (one launch per step), elsewhere their torch.optim twins."""
+    net = getattr(model, 'module', model)
+    groups = {'other': [], 'conv_weight': [], 'bias': []}
+    for name, param in net.named_parameters():
+        kind = 'bias' if '.bias' in name else ('conv_weight' if ('conv' in name and '.weight' in name) else 'other')
+        groups[kind].append(param)
+    first = groups['other']
+    fused = getattr(configs, 'fused_optimizer', True) and bool(first) and first[0].is_cuda
+    if configs.optimizer_type == 'adam':
+        from ..optim import FusedAdam
+        opt = (FusedAdam if fused else torch.optim.Adam)(first, lr=configs.lr)
+    elif configs.optimizer_type == 'sgd':
+        from ..optim import FusedSGD
+        opt = (FusedSGD if fused else torch.optim.SGD)(first, lr=configs.lr, momentum=configs.momentum, nesterov=True)
     else:
-        assert False, "Unknown optimizer type"
-    opt.add_param_group({'params': pg1, 'weight_decay': configs.weight_decay})
-    opt.add_param_group({'params': pg2})
+        raise AssertionError('Unknown optimizer type')
+    opt.add_param_group({'params': groups['conv_weight'], 'weight_decay': configs.weight_decay})
+    opt.add_param_group({'params': groups['bias']})
     return opt
 
 
