@@ -6,6 +6,7 @@ with its per-block ATen calls, and the autograd graph ``total_loss.backward()`` 
 Memory (288 GB HBM3E): every activation, its raw (pre-BN) twin and its gradient are resident for the
 whole step -- nothing is recomputed, nothing is freed between steps.
 """
+import contextlib
 import os
 
 import torch
@@ -114,13 +115,20 @@ class Engine:
         return View(buf, ref.c0, self.N, st.H, st.W, ref.C, st.C, dt)
 
     # ---- forward ---------------------------------------------------------------------------------
+    def _scope(self):
+        """ops.stream_scope on the pass's stream (device engines); a no-op context for the CPU operator simulator."""
+        if getattr(self.device, 'type', str(self.device)) == 'cuda' and hasattr(ops, 'stream_scope'):
+            return ops.stream_scope(torch.cuda.current_stream(self.device))
+        return contextlib.nullcontext()
+
     def forward(self, x, targets, params, use_giou, img_size):
         plan = self.plan
-        ops.nchw_to_nhwc(x, plan.input.C, self.dt, out=self.view(plan.input))
-        self.params = params
-        self._pack_all()
-        for rec in plan.fwd:
-            getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
+        with self._scope():
+            ops.nchw_to_nhwc(x, plan.input.C, self.dt, out=self.view(plan.input))
+            self.params = params
+            self._pack_all()
+            for rec in plan.fwd:
+                getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
         return self.outputs
 
     def _pack_all(self):
@@ -260,12 +268,13 @@ class Engine:
         if self._reduce_groups is None or self._reduce_key != grads[next(iter(grads))].data_ptr():
             self._build_reduce_groups()
         flush_at = {g['last']: g for g in self._reduce_groups}
-        for rec in self.plan.bwd:
-            getattr(self, '_b_' + rec['op'])(rec)
-            if rec['op'] in ('conv_bwd', 'head_conv_bwd'):
-                g = flush_at.get(rec['fwd']['idx'])
-                if g is not None:
-                    self._flush_group(g, on_module_done)
+        with self._scope():
+            for rec in self.plan.bwd:
+                getattr(self, '_b_' + rec['op'])(rec)
+                if rec['op'] in ('conv_bwd', 'head_conv_bwd'):
+                    g = flush_at.get(rec['fwd']['idx'])
+                    if g is not None:
+                        self._flush_group(g, on_module_done)
         if self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
 
@@ -280,7 +289,7 @@ class Engine:
                     on_module_done(idx)
             return
         self.side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.side):
+        with torch.cuda.stream(self.side), ops.stream_scope(self.side):
             ops.wgrad_reduce_multi(g['desc'], g['blocks'], 1.0 / self.ls, True)
             if on_module_done is not None:
                 for idx in g['mods']:
@@ -334,7 +343,7 @@ class Engine:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side.wait_event(ev)
-            with torch.cuda.stream(self.side):
+            with torch.cuda.stream(self.side), ops.stream_scope(self.side):
                 self._wgrad_launch(rec, dy, xv)
             return
         self._wgrad_launch(rec, dy, xv)

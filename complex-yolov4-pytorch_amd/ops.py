@@ -2,6 +2,7 @@
 device tensors / NHWC views and launching on torch's current HIP stream.  PyTorch is used for device
 memory and streams only; every computation below happens in libcyolo_hip.so.  No CPU fallback."""
 import ctypes
+import threading
 
 import torch
 
@@ -100,8 +101,30 @@ def chunk(code):
     return 8 if code == CY_F16 else 4
 
 
+_TLS = threading.local()
+
+
+class stream_scope:
+    """Pins the HIP stream the wrappers launch on for the enclosed calls (thread-local).  torch.cuda.current_stream() costs
+    several microseconds of Python per query; the engine issues ~1200 launches per step on streams it already knows
+    (its pass's stream, or its side stream), so it states them once per section instead of asking per launch."""
+
+    def __init__(self, stream):
+        self.handle = ctypes.c_void_p(stream.cuda_stream)
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, 'handle', None)
+        _TLS.handle = self.handle
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.handle = self.prev
+        return False
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    h = getattr(_TLS, 'handle', None)
+    return h if h is not None else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _p(t):
@@ -113,9 +136,16 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_GPU_SEEN = False
+
+
 def _require_gpu():
+    global _GPU_SEEN
+    if _GPU_SEEN:
+        return
     if not torch.cuda.is_available():
         raise CyoloError('no HIP device: the hot path has no CPU fallback')
+    _GPU_SEEN = True
 
 
 def check_device_tensor(t, who):
