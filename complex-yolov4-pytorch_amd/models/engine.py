@@ -47,6 +47,8 @@ class Engine:
         max_stats = max_bnrows = max_c = 1
         max_wpart = 0
         self.wsplit, self.wslab_off, self.wsplit_cap = {}, {}, {}
+        self._views, self._view_refs = {}, []
+        self._stat_rows = ops.conv_stats_rows(1, 1)
         self._wgrad_tuned = False
         for rec in plan.convs:
             C, M = rec['cout'], N * rec['H'] * rec['W']
@@ -106,13 +108,19 @@ class Engine:
 
     # ---- views -----------------------------------------------------------------------------------
     def view(self, ref, grad=False):
-        st = ref.st
-        if st.kind == 'raw' and not self.training:
-            buf = self.raw_scratch
-        else:
-            buf = (self.gact if grad else self.act)[st.sid]
-        dt = CY_F32 if st.kind == 'logits' else self.dt
-        return View(buf, ref.c0, self.N, st.H, st.W, ref.C, st.C, dt)
+        # views are static (fixed storages): built once per (tensor reference, forward / gradient)
+        key = (id(ref), grad)
+        v = self._views.get(key)
+        if v is None:
+            st = ref.st
+            if st.kind == 'raw' and not self.training:
+                buf = self.raw_scratch
+            else:
+                buf = (self.gact if grad else self.act)[st.sid]
+            dt = CY_F32 if st.kind == 'logits' else self.dt
+            v = self._views[key] = View(buf, ref.c0, self.N, st.H, st.W, ref.C, st.C, dt)
+            self._view_refs.append(ref)     # keeps id(ref) unique for the life of the cache
+        return v
 
     # ---- forward ---------------------------------------------------------------------------------
     def _scope(self):
@@ -187,8 +195,11 @@ class Engine:
         return flops, nbytes
 
     def _names(self, rec):
-        i, n = rec['idx'], rec['n']
-        return 'models.%d.conv%d' % (i, n), 'models.%d.bn%d' % (i, n)
+        nm = rec.get('_names')
+        if nm is None:
+            i, n = rec['idx'], rec['n']
+            nm = rec['_names'] = ('models.%d.conv%d' % (i, n), 'models.%d.bn%d' % (i, n))
+        return nm
 
     def _f_conv(self, rec, targets, use_giou, img_size):
         cname, bname = self._names(rec)
@@ -208,7 +219,7 @@ class Engine:
             with ops.prof('igemm', *self._conv_work(rec)):
                 ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=CONV_STATS,
                                stats=self.stats)
-            ops.bn_finalize(self.stats, ops.conv_stats_rows(M, C), C, M, P[bname + '.weight'], P[bname + '.bias'],
+            ops.bn_finalize(self.stats, self._stat_rows, C, M, P[bname + '.weight'], P[bname + '.bias'],
                             P[bname + '.running_mean'], P[bname + '.running_var'],
                             P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, mean, invstd, scale, shift)
         else:
