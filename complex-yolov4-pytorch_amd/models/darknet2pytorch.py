@@ -53,13 +53,15 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, targets, *params):
         eng = model._engine_for(x)
+        model._weights_epoch += 1            # a training step is under way: cached eval packs are stale from here on
         outputs = eng.forward(x, targets, model._param_table(), model.use_giou_loss, x.shape[2])
         model._publish_metrics(eng)
         heads = [m[0] for m in eng.metrics]
         total = heads[0].clone()
         for h in heads[1:]:
             total += h
-        ctx.model, ctx.eng = model, eng
+        ctx.model, ctx.eng, ctx.fwd_serial = model, eng, eng.fwd_serial
+        outputs = outputs.clone()            # the engine's buffer is overwritten by its next forward
         ctx.mark_non_differentiable(outputs)
         return (total.reshape(1) if model.use_giou_loss else total), outputs
 
@@ -68,6 +70,12 @@ class _StepFn(torch.autograd.Function):
         model, eng = ctx.model, ctx.eng
         if not eng.training:
             raise ops.CyoloError('backward needs model.train(): eval-mode engines keep no activations')
+        if eng.fwd_serial != ctx.fwd_serial:
+            raise ops.CyoloError('backward() of a forward whose saved activations were overwritten: the engine for this '
+                                 'input shape has run another forward since (one forward -> one backward per shape)')
+        accumulating = model._plist is not None and any(p.grad is not None for _, p in model._plist)
+        for hook in model._pre_backward_hooks:
+            hook(model, accumulating)
         grads = model._grad_table()
         eng.backward(grads, gloss.detach().reshape(-1).float().contiguous(), model.loss_scale / model.grad_prescale, act_scale=model.loss_scale,
                      on_module_done=(lambda idx: [h(model, idx) for h in model._module_grad_hooks]) if model._module_grad_hooks else None)
@@ -98,6 +106,12 @@ class Darknet(nn.Module):
         self._plist = None
         self._grad_flat = None
         self._post_backward_hooks = []
+        self._pre_backward_hooks = []    # hook(model, accumulating) before the backward plan touches the flat gradient
+        # eval engines keep packed half-precision weights between forwards; they re-pack when this counter moved (every
+        # training forward, load_state_dict, load_weights, .to()/.half()-style _apply, mark_weights_dirty) -- and on every
+        # eval forward unless static_eval_weights is set (serving: nobody updates parameters behind the model's back)
+        self._weights_epoch = 0
+        self.static_eval_weights = False
         self._module_grad_hooks = []     # called as hook(model, module_idx) when a module's gradients are final
         self.grad_prescale = 1.0         # folded into every parameter-gradient reduction (1/world under data parallelism)
 
@@ -130,6 +144,19 @@ class Darknet(nn.Module):
     def print_network(self):
         print_cfg(self.blocks)
 
+    def mark_weights_dirty(self):
+        """Tell cached eval engines that parameters changed outside Darknet's sight (an in-place edit, an optimizer
+        stepping without a training forward of this module).  Only needed with ``static_eval_weights = True``."""
+        self._weights_epoch += 1
+
+    def load_state_dict(self, *args, **kwargs):
+        self._weights_epoch += 1
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._weights_epoch = getattr(self, '_weights_epoch', 0) + 1
+        return super()._apply(fn, *args, **kwargs)
+
     def load_weights(self, weightfile):
         """Darknet ``.weights`` -> fp32 master parameters and BN running statistics (reference :403-451: int32[5] header,
         ``seen = header[3]``, then per [convolutional] block in cfg order the flat float32 tensors; a short file stops
@@ -140,6 +167,7 @@ class Darknet(nn.Module):
             buf = np.fromfile(fp, dtype=np.float32)
         self.header = torch.from_numpy(header)
         self.seen = self.header[3]
+        self._weights_epoch += 1
         start, ind = 0, -2
         for block in self.blocks:
             if start >= buf.size:
@@ -242,7 +270,8 @@ class Darknet(nn.Module):
         x = x.float().contiguous()
         if targets is None:
             eng = self._engine_for(x)
-            out = eng.forward(x, None, self._param_table(), self.use_giou_loss, x.shape[2])
+            out = eng.forward(x, None, self._param_table(), self.use_giou_loss, x.shape[2],
+                              weights_epoch=self._weights_epoch if self.static_eval_weights else None)
             return out.cpu() if self.cpu_outputs else out.clone()
         targets = targets.to(x.device).float().contiguous()
         if self._plist is None:

@@ -78,7 +78,8 @@ class Engine:
         self.dgs, self.dbs = torch.empty(max_c, **f32), torch.empty(max_c, **f32)
         # split-K slabs of every conv stay resident until their group is folded (table-driven, a few launches per step)
         self.wpart = torch.empty(max(max_wpart, 1), **f32)
-        self._pack_table = self._pack_key = None
+        self._pack_table = self._pack_key = self._pack_epoch = None
+        self.fwd_serial = 0
         self._reduce_groups = None
         use_side = training and getattr(device, 'type', str(device)) == 'cuda' and os.environ.get('CY_WGRAD_SIDE_STREAM', '1') != '0'
         self.side = torch.cuda.Stream(device=device) if use_side else None
@@ -129,31 +130,35 @@ class Engine:
             return ops.stream_scope(torch.cuda.current_stream(self.device))
         return contextlib.nullcontext()
 
-    def forward(self, x, targets, params, use_giou, img_size):
+    def forward(self, x, targets, params, use_giou, img_size, weights_epoch=None):
         plan = self.plan
+        self.fwd_serial += 1
         with self._scope():
             ops.nchw_to_nhwc(x, plan.input.C, self.dt, out=self.view(plan.input))
             self.params = params
-            self._pack_all()
+            self._pack_all(weights_epoch)
             for rec in plan.fwd:
                 getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
         return self.outputs
 
-    def _pack_all(self):
-        """fp32 master weights -> packed f16/f32 matrices of every conv, one table-driven launch.  In eval mode the pack
-        is skipped while no parameter has changed (tensor version counters)."""
+    def _pack_all(self, weights_epoch=None):
+        """fp32 master weights -> packed f16/f32 matrices of every conv, one table-driven launch, on every forward.
+        Only when the model vouches for its parameters (``weights_epoch`` = Darknet._weights_epoch under
+        ``static_eval_weights``) an eval engine skips the pack while that counter stands still.  (Tensor version
+        counters cannot be used: the fused optimizers write through raw pointers and ``p.data`` aliases restart at 0.)"""
         ws = [self.params['models.%d.conv%d.weight' % (r['idx'], r['n'])] for r in self.plan.convs]
         key = tuple(w.data_ptr() for w in ws)
         if self._pack_key != key:
             items = [(w, self.wf[r['idx']], self.wd[r['idx']], _pad32(r['cout']), r['cin_pad']) for w, r in zip(ws, self.plan.convs)]
             self._pack_table = ops.make_pack_table(items, self.device)
             self._pack_key = key
-            self._pack_versions = None
-        if not self.training:
-            versions = tuple(w._version for w in ws)
-            if versions == self._pack_versions:
+            self._pack_epoch = None
+        if not self.training and weights_epoch is not None:
+            if weights_epoch == self._pack_epoch:
                 return
-            self._pack_versions = versions
+            self._pack_epoch = weights_epoch
+        else:
+            self._pack_epoch = None
         ops.pack_weights_multi(self._pack_table[0], self._pack_table[1], self.dt)
 
     def _build_reduce_groups(self):

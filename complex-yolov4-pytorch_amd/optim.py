@@ -16,6 +16,29 @@ class FusedAdam(torch.optim.Optimizer):
         self._table = self._key = None
         self._steps = 0
 
+    def load_state_dict(self, state_dict):
+        """torch.optim semantics plus what the fused step keeps outside ``state``: the bias-correction step count is
+        restored from the per-parameter ``step`` entries (a resumed run continues at t+1, not at t=1) and the kernel
+        table is rebuilt around the loaded moment tensors."""
+        super().load_state_dict(state_dict)
+        self._resync()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._resync()
+
+    def _resync(self):
+        steps = [int(st['step']) for st in self.state.values() if 'step' in st]
+        self._steps = max(steps) if steps else 0
+        self._table = self._key = None
+
+    def note_skipped(self):
+        """A step the device skip flag suppressed (DynamicLossScale found a non-finite gradient) did not happen: take it
+        out of the bias-correction count."""
+        self._steps = max(0, self._steps - 1)
+        for st in self.state.values():
+            st['step'] = self._steps
+
     def _build(self):
         items = []
         for gi, group in enumerate(self.param_groups):
@@ -28,7 +51,7 @@ class FusedAdam(torch.optim.Optimizer):
                     st['exp_avg_sq'] = torch.zeros_like(p.data)
                     st['step'] = 0
                 items.append((p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], gi))
-        key = tuple((i[0].data_ptr(), i[1].data_ptr(), i[4]) for i in items)
+        key = tuple((i[0].data_ptr(), i[1].data_ptr(), i[2].data_ptr(), i[3].data_ptr(), i[4]) for i in items)
         if key != self._key:
             self._table = ops.make_adam_table(items, items[0][0].device) if items else None
             self._key = key
@@ -62,7 +85,17 @@ class FusedSGD(torch.optim.Optimizer):
             raise ValueError('Nesterov momentum requires a momentum and zero dampening')
         super().__init__(params, dict(lr=lr, momentum=momentum, nesterov=nesterov, weight_decay=weight_decay, dampening=0))
         self._table = self._key = None
-        self._steps = 0
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._table = self._key = None      # the loaded momentum buffers are new tensors
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._table = self._key = None
+
+    def note_skipped(self):
+        pass
 
     def _build(self):
         items, fresh = [], False
@@ -75,7 +108,7 @@ class FusedSGD(torch.optim.Optimizer):
                     st['momentum_buffer'] = torch.zeros_like(p.data)
                     fresh = True
                 items.append((p.data, p.grad, st['momentum_buffer'], st['momentum_buffer'], gi))
-        key = tuple((i[0].data_ptr(), i[1].data_ptr(), i[4]) for i in items)
+        key = tuple((i[0].data_ptr(), i[1].data_ptr(), i[2].data_ptr(), i[4]) for i in items)
         if key != self._key:
             self._table = ops.make_adam_table(items, items[0][0].device) if items else None
             self._key = key
@@ -84,16 +117,16 @@ class FusedSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, zero_grad=False):
         loss = closure() if closure is not None else None
-        fresh = self._build()
+        self._build()
         if self._table is None:
             return loss
         g0 = self.param_groups[0]
         for g in self.param_groups:
             assert g['momentum'] == g0['momentum'] and g['nesterov'] == g0['nesterov'], 'momentum/nesterov must be shared'
         assert len(self.param_groups) <= 8
-        first = self._steps == 0 or fresh
-        self._steps += 1
-        ops.sgd_multi(self._table[0], self._table[1], g0['momentum'], g0['nesterov'], first,
+        # torch's first step sets buf = g; with the zero-initialised buffers of _build that IS buf = momentum * buf + g,
+        # so no step is special -- and a momentum buffer restored by load_state_dict is never overwritten
+        ops.sgd_multi(self._table[0], self._table[1], g0['momentum'], g0['nesterov'], False,
                       [g['lr'] for g in self.param_groups], [g['weight_decay'] for g in self.param_groups], zero_grad=zero_grad,
                       skip_flag=getattr(self, 'skip_flag', None))
         return loss
@@ -147,6 +180,8 @@ class DynamicLossScale:
                 self.model.loss_scale = max(self.model.loss_scale * self.backoff_factor, 2.0 ** -14)
                 self._clean = 0
                 self.skipped += 1
+                if hasattr(self.optimizer, 'note_skipped'):
+                    self.optimizer.note_skipped()
             else:
                 self._clean += 1
                 if self._clean >= self.growth_interval:

@@ -13,9 +13,27 @@ src/train.py:67,212) and its per-iteration loss all-reduce (src/utils/train_util
     the reference too (no SyncBN) and rank 0's are the ones checkpointed (train_utils.py:82-85);
   * the 1/world of the mean is folded into the backward kernels' gradient reductions (no extra pass over 256 MB);
   * the loss scalar is reduced only when asked (``reduce_tensor``), not as a side effect.
+
+Gradient accumulation over sub-divisions (reference train.py:212-221: ``backward()`` every batch, ``optimizer.step()``
+every ``subdivisions`` batches).  The flat buffer is accumulated into across backwards, and a SUM all-reduce is only
+idempotent on contributions that have not been reduced yet, so the buffer's form is tracked:
+
+    EMPTY    zero_grad() happened (every ``.grad`` is None at the next backward)
+    LOCAL    holds sum_i g_i(this rank) / world -- not reduced yet (after a backward under ``no_sync()``)
+    REDUCED  holds sum_i mean_over_ranks(g_i)  -- identical on every rank (after a synchronised backward)
+
+A backward that finds the buffer REDUCED first rescales it by 1/world (one pass over 256 MB, ~0.1 ms): the SUM over
+ranks of R/world is R again, so the all-reduce of ``R/world + g_local/world`` yields ``R + mean(g)``.  ``no_sync()``
+(same contract as DistributedDataParallel.no_sync) skips the collectives of the enclosed backwards; with it a
+sub-divided step costs ONE all-reduce and no rescale -- ``accumulate(model, i, subdivisions)`` picks the right context
+for micro-batch i.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
+
+EMPTY, LOCAL, REDUCED = 'empty', 'local', 'reduced'
 
 
 class RcclDataParallel(torch.nn.Module):
@@ -32,6 +50,9 @@ class RcclDataParallel(torch.nn.Module):
         self._offsets = None
         self._tail = None
         self._pending = []
+        self._sync = True
+        self._form = EMPTY
+        module._pre_backward_hooks.append(self._pre_backward)
         module._post_backward_hooks.append(self._finish)
         module._module_grad_hooks.append(self._module_done)
         if self.active:
@@ -46,6 +67,25 @@ class RcclDataParallel(torch.nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backwards inside accumulate locally (no collective); the next backward outside reduces the lot."""
+        prev, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = prev
+
+    def _pre_backward(self, model, accumulating):
+        """Runs before the backward plan adds this micro-batch's gradients (see the module docstring)."""
+        if not self.active:
+            return
+        if not accumulating:
+            self._form = EMPTY
+        elif self._form == REDUCED:
+            model.flat_grad.mul_(1.0 / self.world)
+            self._form = LOCAL
+
     # ---- bucketed all-reduce -----------------------------------------------------------------------
     def _prepare(self):
         named = list(self.module.named_parameters())
@@ -59,7 +99,7 @@ class RcclDataParallel(torch.nn.Module):
 
     def _reduce_range(self, lo, hi):
         flat = self.module.flat_grad
-        if flat is None or hi <= lo or not self.active:
+        if flat is None or hi <= lo or not self.active or not self._sync:
             return
         chunk = flat[lo:hi]
         if flat.is_cuda:
@@ -93,6 +133,7 @@ class RcclDataParallel(torch.nn.Module):
             self._prepare()
         self._reduce_range(0, self._tail)
         self._tail = self._total
+        self._form = REDUCED if self._sync else LOCAL
         flat = model.flat_grad
         if flat is not None and flat.is_cuda and self._side is not None:
             torch.cuda.current_stream(flat.device).wait_stream(self._side)
@@ -105,6 +146,14 @@ def reduce_tensor(tensor, world_size):
         dist.all_reduce(rt, op=dist.ReduceOp.SUM)
         rt /= world_size
     return rt
+
+
+def accumulate(model, micro_step, subdivisions):
+    """Context for micro-batch ``micro_step`` (0-based) of a ``subdivisions``-fold accumulated step: ``no_sync()`` for all
+    but the last one when ``model`` is an RcclDataParallel, a null context otherwise."""
+    if isinstance(model, RcclDataParallel) and (micro_step + 1) % max(1, subdivisions) != 0:
+        return model.no_sync()
+    return contextlib.nullcontext()
 
 
 def subdivisions_for(batch_size, ngpus_per_node):

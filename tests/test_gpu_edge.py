@@ -176,7 +176,7 @@ def test_bev_rasteriser_golden_and_edges(golden):
     ref[:, g['pixels']] = g['values']
     ref = ref.reshape(3, 608, 608)
     # raw points on the device, one fused pass
-    got = bev.makeBVFeature(torch.from_numpy(pts).cuda(), cnf.DISCRETIZATION, cnf.boundary)
+    got = bev.makeBVFeature(torch.from_numpy(pts).cuda(), cnf.DISCRETIZATION, cnf.boundary, raw=True)
     assert got.is_cuda and got.dtype == torch.float32 and got.shape == (3, 608, 608)
     got = got.cpu().numpy()
     np.testing.assert_array_equal(got[0], ref[0])
@@ -189,14 +189,17 @@ def test_bev_rasteriser_golden_and_edges(golden):
     got2 = bev.makeBVFeature(b, cnf.DISCRETIZATION, cnf.boundary)
     assert isinstance(got2, np.ndarray) and got2.dtype == np.float64
     np.testing.assert_array_equal(got2.astype(np.float32)[:2], ref[:2])
+    # the filtered points survive any container change (np.copy / torch tensor / device tensor): no hidden tag
+    got3 = bev.makeBVFeature(torch.from_numpy(np.array(b, dtype=np.float32)).cuda().float(), cnf.DISCRETIZATION, cnf.boundary)
+    np.testing.assert_array_equal(got3.cpu().numpy()[:2], ref[:2])
     # the workspace is left clean: a second frame is not polluted by the first; empty cloud -> zeros
-    again = bev.makeBVFeature(torch.from_numpy(pts).cuda(), cnf.DISCRETIZATION, cnf.boundary).cpu().numpy()
+    again = bev.makeBVFeature(torch.from_numpy(pts).cuda(), cnf.DISCRETIZATION, cnf.boundary, raw=True).cpu().numpy()
     np.testing.assert_array_equal(again, got)
     empty = bev.makeBVFeature(torch.zeros(0, 4).cuda(), cnf.DISCRETIZATION, cnf.boundary)
     assert float(empty.abs().sum()) == 0.0
     # a full-size scan (120k points, KITTI-like) against the oracle
     big = lidar_points(120000, seed=5)
     o = bev_ref.make_bv_feature(bev_ref.remove_points(big.copy(), cnf.boundary), cnf.DISCRETIZATION, cnf.boundary).astype(np.float32)
-    gb = bev.makeBVFeature(torch.from_numpy(big).cuda(), cnf.DISCRETIZATION, cnf.boundary).cpu().numpy()
+    gb = bev.makeBVFeature(torch.from_numpy(big).cuda(), cnf.DISCRETIZATION, cnf.boundary, raw=True).cpu().numpy()
     np.testing.assert_array_equal(gb[:2], o[:2])
     np.testing.assert_allclose(gb[2], o[2], rtol=2e-7, atol=0)

@@ -442,6 +442,44 @@ def test_fused_sgd_matches_torch_sgd(nesterov):
         torch.testing.assert_close(mine.state[b]['momentum_buffer'], ref.state[a]['momentum_buffer'], rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize('kind', ['adam', 'sgd'])
+def test_fused_optimizer_resume_from_state_dict(kind):
+    """after optimizer.load_state_dict (resume from a Utils_*.pth, reference train.py:123-133) the
+    fused optimizers continue exactly like torch's: Adam's bias correction goes on at t+1 (not t = 1) and SGD's
+    restored momentum buffer is used, not overwritten by the first gradient."""
+    from complex_yolov4_pytorch_amd.optim import FusedAdam, FusedSGD
+    shapes = [(32, 16, 3, 3), (32,), (500,)]
+
+    def make(ps):
+        if kind == 'adam':
+            return torch.optim.Adam(ps, lr=1e-2), FusedAdam
+        return torch.optim.SGD(ps, lr=1e-2, momentum=0.9, nesterov=True), FusedSGD
+    ref_p = [_rand(*s, seed=270 + i).to(DEV).requires_grad_(True) for i, s in enumerate(shapes)]
+    my_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    ref, cls = make(ref_p)
+    kw = dict(lr=1e-2) if kind == 'adam' else dict(lr=1e-2, momentum=0.9, nesterov=True)
+    mine = cls(my_p, **kw)
+
+    def step(opts_params, seed):
+        for opt, ps in opts_params:
+            for i, p_ in enumerate(ps):
+                p_.grad = _rand(*p_.shape, seed=seed + i).to(DEV)
+            opt.step()
+    for t in range(4):
+        step(((ref, ref_p), (mine, my_p)), 400 + 10 * t)
+    import copy
+    sd = copy.deepcopy(mine.state_dict())
+    my_p2 = [p.detach().clone().requires_grad_(True) for p in my_p]
+    resumed = cls(my_p2, **kw)
+    resumed.load_state_dict(sd)
+    for t in range(4, 7):
+        step(((ref, ref_p), (resumed, my_p2)), 400 + 10 * t)
+    for a, b in zip(ref_p, my_p2):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6)
+    if kind == 'adam':
+        assert all(int(st['step']) == 7 for st in resumed.state.values())
+
+
 @pytest.mark.parametrize('dt', [CY_F16, CY_F32])
 @pytest.mark.parametrize('act', ['mish', 'leaky', 'linear'])
 def test_conv_bn_act_eval_fused(dt, act):

@@ -147,3 +147,66 @@ def test_cpu_input_is_refused():
     model = Darknet(os.path.join(CFG, 'complex_yolov4_tiny.cfg'), use_giou_loss=True)
     with pytest.raises(CyoloError):
         model(torch.zeros(1, 3, 96, 96))
+
+
+def _mini(monkeypatch):
+    from tests.util import mini_cfg_path
+    opsim.install(monkeypatch)
+    torch.manual_seed(3)
+    m = Darknet(mini_cfg_path(), use_giou_loss=True, dtype='f32')
+    return m
+
+
+def test_eval_engine_sees_updated_weights(monkeypatch):
+    """train -> eval -> step -> eval.  The cached eval engine must use the CURRENT conv weights, also
+    when they were changed in place (optimizers, load_state_dict and load_weights all write through the same storage)."""
+    m = _mini(monkeypatch)
+    m.cpu_outputs = False
+    x, tg = syn.bev_images(2, 64, seed=4, sparsity=0.5), syn.targets(2, 3, 64, seed=4)
+    m.eval()
+    out0 = m(x).clone()
+    assert torch.equal(m(x), out0)
+    with torch.no_grad():                                     # in-place update: same data_ptr, version counters useless
+        for n, p in m.named_parameters():
+            if n.endswith('conv1.weight') or n.endswith('conv3.weight'):
+                p.mul_(1.5)
+    out1 = m(x).clone()
+    assert float((out1 - out0).abs().max()) > 1e-3
+    m.release_engines()
+    torch.testing.assert_close(m(x), out1, rtol=0, atol=0)     # a fresh engine agrees with the cached one
+    # opt-in static weights: the pack is skipped until something the model can see changes the parameters
+    m.static_eval_weights = True
+    out2 = m(x).clone()
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    m.train()
+    loss, _ = m(x, tg)
+    loss.backward()
+    opt.step()
+    m.eval()
+    out3 = m(x).clone()
+    assert float((out3 - out2).abs().max()) > 1e-4             # the training forward invalidated the cached pack
+    m.release_engines()
+    torch.testing.assert_close(m(x), out3, rtol=0, atol=0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        sd['models.0.conv1.weight'] *= 0.5
+    m.load_state_dict(sd)
+    out4 = m(x).clone()
+    assert float((out4 - out3).abs().max()) > 1e-4
+
+
+def test_training_outputs_are_not_aliased_and_stale_backward_raises(monkeypatch):
+    """yolo_outputs returned in training survive the next forward; a backward through activations that a
+    later forward of the same engine overwrote is refused instead of silently using the wrong tensors."""
+    from complex_yolov4_pytorch_amd.ops import CyoloError
+    m = _mini(monkeypatch)
+    m.train()
+    xa, ta = syn.bev_images(2, 64, seed=5, sparsity=0.5), syn.targets(2, 3, 64, seed=5)
+    xb, tb = syn.bev_images(2, 64, seed=6, sparsity=0.5), syn.targets(2, 3, 64, seed=6)
+    loss_a, out_a = m(xa, ta)
+    keep = out_a.clone()
+    loss_b, out_b = m(xb, tb)
+    assert torch.equal(out_a, keep) and not torch.equal(out_a, out_b)
+    with pytest.raises(CyoloError):
+        loss_a.backward()
+    loss_b.backward()                                          # the latest forward is fine
