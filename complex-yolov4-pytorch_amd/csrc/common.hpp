@@ -9,6 +9,9 @@ typedef _Float16 f16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -37,6 +40,11 @@ struct Elem<f16> {
     static constexpr int DT = CY_F16;
 };
 template <>
+struct Elem<bf16> {
+    static constexpr int CH = 8;
+    static constexpr int DT = CY_BF16;
+};
+template <>
 struct Elem<float> {
     static constexpr int CH = 4;
     static constexpr int DT = CY_F32;
@@ -52,6 +60,15 @@ __device__ __forceinline__ void chunk_to_f32<f16>(const u32x4& v, float* f) {
     for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
 }
 template <>
+__device__ __forceinline__ void chunk_to_f32<bf16>(const u32x4& v, float* f) {
+    // bf16 -> f32 is a 16-bit shift: exact, two VALU per pair
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xFFFF0000u);
+    }
+}
+template <>
 __device__ __forceinline__ void chunk_to_f32<float>(const u32x4& v, float* f) {
     const f32x4 h = __builtin_bit_cast(f32x4, v);
 #pragma unroll
@@ -64,6 +81,13 @@ __device__ __forceinline__ u32x4 f32_to_chunk<f16>(const float* f) {
     f16x8 h;
 #pragma unroll
     for (int i = 0; i < 8; ++i) h[i] = (f16)f[i];
+    return __builtin_bit_cast(u32x4, h);
+}
+template <>
+__device__ __forceinline__ u32x4 f32_to_chunk<bf16>(const float* f) {
+    bf16x8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (bf16)f[i];     // round to nearest even (v_cvt_pk_bf16_f32 on gfx950)
     return __builtin_bit_cast(u32x4, h);
 }
 template <>

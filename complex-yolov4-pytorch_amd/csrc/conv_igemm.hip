@@ -13,9 +13,9 @@
 // f16: v_mfma_f32_16x16x32_f16.  f32 (parity mode): v_mfma_f32_16x16x4_f32, exact f32.
 //
 // Two kernels share the scheme: igemm_fast_kernel (Cin a multiple of the K step: wave-uniform tap per
-// step, SGPR offsets) runs every layer but the first two; igemm_kernel (per-lane tap, any Cin, also
-// the register-staged and 3-stage / 512-thread experiment variants) runs the rest.  CY_IGEMM_* environment
-// variables select variants and timing experiments.
+// step, SGPR offsets) and igemm_kernel (per-lane tap, any Cin: the first layers).  The 16-bit modes hand
+// every launch that qualifies to the 8-wave pipelined kernel of conv_pipe.hip first; what stays here is
+// the f32 parity mode, the fp32-output head convs, the first layers and grids too small for 256-pixel tiles.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -24,9 +24,9 @@
 namespace {
 using namespace cyk;
 
-template <typename T, int BM, int BN, bool GLDS, int NST = 2, int NW = 4>
-__global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
-    static_assert(NST == 2 || GLDS, "the 3-stage ring needs direct-to-LDS loads");
+template <typename T, int BM, int BN>
+__global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
+    constexpr int NW = 4;
     constexpr int CH = Elem<T>::CH;
     constexpr int BK = 8 * CH;
     constexpr int NT = NW * 64, RS = NW * 8;  // threads; tile rows staged per pass (8 rows of 128 B per wave instruction)
@@ -52,11 +52,10 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
     const int tn = lid % p.ntiles, tm = lid / p.ntiles;
 
     // ---- per-thread staging coordinates --------------------------------------------------------
-    // register staging: thread = (row tid>>3, chunk tid&7), swizzle applied on the LDS store.
-    // direct-to-LDS (GLDS): the LDS image of a wave-instruction is lane-linear (base + lane*16), so the swizzle moves to
+    // direct-to-LDS: the LDS image of a wave-instruction is lane-linear (base + lane*16), so the swizzle moves to
     // the SOURCE: lane l fills physical chunk l&7 of row l>>3, i.e. it fetches logical chunk (l&7)^(row&7).
-    const int chunk = GLDS ? ((lane & 7) ^ ((p.dbg_nomma & 2) ? 0 : ((lane >> 3) & 7))) : (tid & 7);   // dbg bit 1: no source swizzle (timing experiment only)
-    const int rbase = GLDS ? (wave * 8 + (lane >> 3)) : (tid >> 3);
+    const int chunk = (lane & 7) ^ ((lane >> 3) & 7);
+    const int rbase = wave * 8 + (lane >> 3);
     // Per row (pixel) of this thread: byte offset of the "tap (0,0)" source pixel and a bit mask of the taps that fall
     // inside the image (and, for dgrad, on the stride lattice).  Per K step only  base + delta(tap) + channel  is left.
     const int ksign = p.transposed ? -1 : 1;
@@ -108,14 +107,11 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
     const auto rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFF00u;
-    (void)rs_g; (void)rs_w;
 
-    u32x4 xv[XR], wv[WR];
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto load_tile = [&](int kt, int stage) {
         unsigned char* xs_w = smem + stage * STAGE + wave_u * (8 * 128);
         unsigned char* ws_w = xs_w + BM * 128;
-        (void)xs_w; (void)ws_w;
         const bool kvalid = k_tap < ntaps;
         const int tsh = 2 * min(k_tap, 15);
         const int kh = (p.kh_pack >> tsh) & 3, kw = (p.kw_pack >> tsh) & 3;
@@ -124,30 +120,18 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
             const bool ok = kvalid & ((x_mask[i] >> k_tap) & 1u);
-            if constexpr (GLDS) {
-                const unsigned off = ok ? x_base[i] + tap_delta : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(xs_w + i * (RS * 128)),
-                                                         16, off, 0, 0, 0);
-            } else {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (ok) v = *reinterpret_cast<const u32x4*>(p.g + (size_t)(x_base[i] + tap_delta));
-                xv[i] = v;
-            }
+            const unsigned off = ok ? x_base[i] + tap_delta : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(xs_w + i * (RS * 128)),
+                                                     16, off, 0, 0, 0);
         }
         const unsigned koff = (unsigned)((kh * p.ks + kw) * p.GC + k_c) * (unsigned)sizeof(T);  // column of the packed weights
         (void)kt;
 #pragma unroll
         for (int i = 0; i < WR; ++i) {
             const bool ok = kvalid & (tn * BN + rbase + RS * i < p.wrows);
-            if constexpr (GLDS) {
-                const unsigned off32 = ok ? w_row0 + i * w_rstep + koff : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(ws_w + i * (RS * 128)),
-                                                         16, off32, 0, 0, 0);
-            } else {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (ok) v = *reinterpret_cast<const u32x4*>(p.w + (size_t)(w_row0 + i * w_rstep + koff));
-                wv[i] = v;
-            }
+            const unsigned off32 = ok ? w_row0 + i * w_rstep + koff : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(ws_w + i * (RS * 128)),
+                                                     16, off32, 0, 0, 0);
         }
         // advance this thread's chunk to the next K tile (branch-free: BK = adv_tap * GC + adv_c)
         k_tap += adv_tap;
@@ -156,29 +140,13 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
         k_c -= wrap ? p.GC : 0;
         k_tap += wrap ? 1 : 0;
     };
-    auto store_tile = [&](int stage) {
-        if constexpr (GLDS) return;
-        unsigned char* xs = smem + stage * STAGE;
-        unsigned char* ws = xs + BM * 128;
-#pragma unroll
-        for (int i = 0; i < XR; ++i) {
-            const int row = rbase + RS * i;
-            *reinterpret_cast<u32x4*>(xs + row * 128 + ((chunk ^ (row & 7)) << 4)) = xv[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            const int row = rbase + RS * i;
-            *reinterpret_cast<u32x4*>(ws + row * 128 + ((chunk ^ (row & 7)) << 4)) = wv[i];
-        }
-    };
-
     f32x4 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (p.dbg_nomma & 16) ? 1 : (p.ntaps * p.GC + BK - 1) / BK;   // dbg bit 4: one K step (fixed-cost experiment)
+    const int nkt = (p.ntaps * p.GC + BK - 1) / BK;
     auto compute_tile = [&](int stage) {
         const unsigned char* xs = smem + stage * STAGE;
         const unsigned char* ws = xs + BM * 128;
@@ -197,33 +165,16 @@ __global__ void __launch_bounds__(NW * 64) igemm_kernel(const IgemmParams p) {
                 for (int j = 0; j < TJ; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
         }
     };
-    if constexpr (NST == 2) {
-        load_tile(0, 0);
-        store_tile(0);
+    load_tile(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1, cur ^ 1);
+        compute_tile(cur);
         __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nkt && !(p.dbg_nomma & 32)) load_tile(kt + 1, cur ^ 1);   // dbg bit 5: no loads in the loop
-            if (!(p.dbg_nomma & 1)) compute_tile(cur);
-            if (kt + 1 < nkt) store_tile(cur ^ 1);
-            __syncthreads();
-        }
-    } else {
-        // 3-stage ring of direct-to-LDS tiles: two tiles in flight across the barrier (counted vmcnt + raw s_barrier;
-        // __syncthreads() would drain the DMA queue).  Tile kt is consumed one barrier after the wait that retires it.
-        constexpr int LPT = XR + WR;  // DMA instructions per tile per wave
-        load_tile(0, 0);
-        if (nkt > 1) load_tile(1, 1);
-        for (int kt = 0; kt < nkt; ++kt) {
-            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nkt) load_tile(kt + 2, (kt + 2) % 3);
-            compute_tile(kt % 3);
-        }
     }
 
-    igemm_epilogue<T, BM, BN, NW, NST != 2>(p, acc, tm, tn, lid, smem);
+    igemm_epilogue<T, BM, BN, NW, false>(p, acc, tm, tn, lid, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -391,34 +342,22 @@ __global__ void __launch_bounds__(256, 2) igemm_fast_kernel(const IgemmParams p)
     igemm_epilogue<T, BM, BN, NW, false>(p, acc, tm, tn, lid, smem);
 }
 
-template <typename T, int BM, int BN, bool GLDS, int NST, int NW = 4>
-int launch_v(const IgemmParams& p0, hipStream_t s) {
+template <typename T, int BM, int BN>
+int launch_general(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.OC + BN - 1) / BN;
-    static int lds_pad = -1;   // CY_IGEMM_LDS_PAD=bytes: occupancy experiments (forces fewer resident blocks per CU)
-    if (lds_pad < 0) { const char* e = getenv("CY_IGEMM_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
-    const int smem = NST * (BM + BN) * 128 + lds_pad;
+    if (p.stat_rows != 64) p.stat_rows = p.mtiles;
+    constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GLDS, NST, NW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, GLDS, NST, NW>), dim3(p.mtiles * p.ntiles), dim3(NW * 64), smem, s, p);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, s, p);
     CY_LAUNCH_CHECK();
     return 0;
-}
-
-// CY_IGEMM_GLDS=0 selects the register-staged double buffer (kept for A/B measurements on the 64/128-pixel tiles);
-// default is the direct-to-LDS double buffer.  A 3-stage DMA ring (NST = 3) measured slower at equal LDS footprint.
-inline int glds_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("CY_IGEMM_GLDS");
-        v = e ? atoi(e) : 1;
-    }
-    return v;
 }
 
 template <typename T, int BM, int BN>
@@ -426,6 +365,7 @@ int launch_fast(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.OC + BN - 1) / BN;
+    if (p.stat_rows != 64) p.stat_rows = p.mtiles;
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
@@ -438,29 +378,11 @@ int launch_fast(const IgemmParams& p0, hipStream_t s) {
     return 0;
 }
 
-inline int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 template <typename T, int BM, int BN>
 int launch(const IgemmParams& p, hipStream_t s) {
-    if constexpr (sizeof(T) == 2 && BN == 128 && (BM == 128 || BM == 256)) {
-        // experiment variants: CY_IGEMM_NST=3 (three-stage DMA ring), CY_IGEMM_NW=8 (512-thread blocks)
-        static const int nst = env_int("CY_IGEMM_NST", 2), nw = env_int("CY_IGEMM_NW", 4);
-        if (nst == 3 && nw == 8) return launch_v<T, BM, BN, true, 3, 8>(p, s);
-        if (nst == 3) return launch_v<T, BM, BN, true, 3, 4>(p, s);
-        if (nw == 8) return launch_v<T, BM, BN, true, 2, 8>(p, s);
-    }
-    if constexpr (BM == 128 || BM == 64) {
-        if (glds_mode() == 0) return launch_v<T, BM, BN, false, 2>(p, s);
-    }
-    {   // uniform-tap fast path (CY_IGEMM_FAST=0 keeps the general kernel for A/B runs)
-        static const int fast = env_int("CY_IGEMM_FAST", 1);
-        constexpr int BK = 8 * Elem<T>::CH;
-        if (fast && p.x_bias && p.GC % BK == 0 && p.dbg_nomma == 0) return launch_fast<T, BM, BN>(p, s);
-    }
-    return launch_v<T, BM, BN, true, 2>(p, s);
+    constexpr int BK = 8 * Elem<T>::CH;
+    if (p.x_bias && p.GC % BK == 0) return launch_fast<T, BM, BN>(p, s);   // wave-uniform tap per K step
+    return launch_general<T, BM, BN>(p, s);
 }
 
 // Tile choice.  Channel tile = min(128, OC rounded up to 32).  Pixel tile: blocks run in rounds of 256 * blocks-per-CU
@@ -491,25 +413,25 @@ inline void pick_tile(int M, int OC, int K, int esize, int& bm, int& bn) {
 }
 
 template <typename T>
-int dispatch(const IgemmParams& p, hipStream_t s) {
+int dispatch_tiles(const IgemmParams& p, hipStream_t s) {
     int bm, bn;
     pick_tile(p.M, p.OC, p.ntaps * p.GC, (int)sizeof(T), bm, bn);
-    {   // CY_IGEMM_TILE=BMxBN forces a tile (tuning experiments)
-        static int fbm = -1, fbn = -1;
-        if (fbm < 0) {
-            const char* e = getenv("CY_IGEMM_TILE");
-            fbm = fbn = 0;
-            if (e) sscanf(e, "%dx%d", &fbm, &fbn);
-        }
-        if (fbm > 0) { bm = fbm; bn = fbn; }
-    }
 #define CY_TILE(BM_, BN_) \
     if (bm == BM_ && bn == BN_) return launch<T, BM_, BN_>(p, s);
     CY_TILE(128, 128) CY_TILE(128, 64) CY_TILE(128, 32) CY_TILE(64, 128) CY_TILE(64, 64) CY_TILE(64, 32)
-    CY_TILE(192, 128) CY_TILE(192, 64) CY_TILE(160, 128) CY_TILE(160, 64) CY_TILE(96, 128) CY_TILE(96, 64) CY_TILE(256, 64)
-    CY_TILE(256, 128)
+    CY_TILE(192, 128) CY_TILE(192, 64)
 #undef CY_TILE
     return CY_ERR_ARG;
+}
+
+// one launch: the pipelined kernel when the shape qualifies, else the 4-wave kernels of this file
+int dispatch(const IgemmParams& p, int dtype, hipStream_t s) {
+    int used = 0;
+    const int rc = cy_pipe_try(p, dtype, s, &used);
+    if (rc || used) return rc;
+    if (dtype == CY_F16) return dispatch_tiles<f16>(p, s);
+    if (dtype == CY_BF16) return dispatch_tiles<bf16>(p, s);
+    return dispatch_tiles<float>(p, s);
 }
 
 }  // namespace
@@ -519,33 +441,36 @@ extern "C" int cy_conv_stats_rows(int M, int OC) {
     return 64;
 }
 
+// CY_CONV_STATS_DET: one table row per pixel tile; no kernel uses tiles of fewer than 64 pixels
+extern "C" int cy_conv_stats_rows_det(int M, int OC) {
+    (void)OC;
+    return (M + 63) / 64;
+}
+
 static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out,
                            int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags,
                            const float* bias, float* stats_part, int* stats_rows_host, const float* aff_scale,
                            const float* aff_shift, int act, const void* res, int ldres, cy_stream_t s) {
-    const int ch = dtype == CY_F16 ? 8 : 4;
-    if (!g || !w || !out || (dtype != CY_F16 && dtype != CY_F32)) return CY_ERR_ARG;
+    const int ch = dtype == CY_F32 ? 4 : 8;
+    if (!g || !w || !out || (dtype != CY_F16 && dtype != CY_BF16 && dtype != CY_F32)) return CY_ERR_ARG;
     if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2) || GC % ch || ldg % ch) return CY_ERR_ARG;
     if ((flags & CY_CONV_STATS) && !stats_part) return CY_ERR_ARG;
+    if ((flags & CY_CONV_STATS_DET) && !(flags & CY_CONV_STATS)) return CY_ERR_ARG;
     if (!(flags & CY_CONV_BIAS_F32OUT) && (ldo % 4)) return CY_ERR_ARG;
     IgemmParams p;
     p.g = (const unsigned char*)g; p.w = (const unsigned char*)w; p.o = (unsigned char*)out;
     p.bias = bias; p.stats = stats_part;
-    {
-        static int nomma = -1;
-        if (nomma < 0) { const char* e = getenv("CY_IGEMM_NOMMA"); nomma = e ? atoi(e) : 0; }
-        p.dbg_nomma = nomma;
-    }
     p.aff_scale = aff_scale; p.aff_shift = aff_shift; p.act = act; p.res = (const unsigned char*)res; p.ldres = ldres;
     if ((flags & CY_CONV_AFFINE_ACT) && (!aff_scale || !aff_shift || (flags & (CY_CONV_STATS | CY_CONV_TRANSPOSED)))) return CY_ERR_ARG;
     p.N = N; p.GH = GH; p.GW = GW; p.GC = GC; p.ldg = ldg;
     p.OH = OH; p.OW = OW; p.OC = OC; p.ldo = ldo;
     p.ks = ks; p.stride = stride; p.pad = pad; p.transposed = (flags & CY_CONV_TRANSPOSED) ? 1 : 0;
     p.K = ks * ks * GC; p.M = N * OH * OW; p.wrows = wrows; p.flags = flags;
-    p.mtiles = p.ntiles = 0; p.halo_xbuf = p.halo_pieces = 0;
+    p.mtiles = p.ntiles = 0; p.bm_eff = 0;
+    p.stat_rows = (flags & CY_CONV_STATS_DET) ? 0 : 64;
     if (p.M <= 0 || OC <= 0) return CY_ERR_ARG;
-    if (stats_rows_host) *stats_rows_host = cy_conv_stats_rows(p.M, OC);
-    const size_t esz = dtype == CY_F16 ? 2 : 4;
+    if (stats_rows_host) *stats_rows_host = (flags & CY_CONV_STATS_DET) ? cy_conv_stats_rows_det(p.M, OC) : cy_conv_stats_rows(p.M, OC);
+    const size_t esz = dtype == CY_F32 ? 4 : 2;
     const size_t gb = (((size_t)N * GH * GW - 1) * ldg + GC) * esz, wb = (size_t)wrows * p.K * esz;
     if (gb >= 0xFFFFFF00ull || wb >= 0xFFFFFF00ull) return CY_ERR_ARG;  // 32-bit buffer offsets
     p.g_bytes = (unsigned)gb; p.w_bytes = (unsigned)wb;
@@ -559,12 +484,7 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
         p.kh_pack |= (unsigned)(t / ks) << (2 * t);
         p.kw_pack |= (unsigned)(t % ks) << (2 * t);
     }
-    if (!(p.transposed && stride == 2)) {
-        int used = 0;
-        const int rc = cy_halo3x3_try(p, dtype, cy_s(s), &used);
-        if (rc || used) return rc;
-        return dtype == CY_F16 ? dispatch<f16>(p, cy_s(s)) : dispatch<float>(p, cy_s(s));
-    }
+    if (!(p.transposed && stride == 2)) return dispatch(p, dtype, cy_s(s));
     // stride-2 dgrad: an input-gradient pixel only sees the taps with (o + pad - k) even.  Four launches, one per
     // (row, column) parity class, each over its own taps: 9 tap-visits in total instead of 36.
     for (int ph = 0; ph < 2; ++ph)
@@ -584,7 +504,7 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
                     ++q.ntaps;
                 }
             }
-            const int rc = dtype == CY_F16 ? dispatch<f16>(q, cy_s(s)) : dispatch<float>(q, cy_s(s));
+            const int rc = dispatch(q, dtype, cy_s(s));
             if (rc) return rc;
         }
     return 0;
@@ -602,8 +522,9 @@ extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int l
 extern "C" int cy_conv_bn_act_eval(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows,
                                    void* out, int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype,
                                    const float* scale, const float* shift, int act, const void* res, int ldres,
-                                   cy_stream_t s) {
+                                   int flags, cy_stream_t s) {
     CY_ENTER();
+    if (flags & ~CY_CONV_TILE(15)) return CY_ERR_ARG;      // only the kernel / tile hint is accepted here
     return conv_igemm_impl(g, N, GH, GW, GC, ldg, w, wrows, out, OH, OW, OC, ldo, ks, stride, pad, dtype,
-                           CY_CONV_AFFINE_ACT, nullptr, nullptr, nullptr, scale, shift, act, res, ldres, s);
+                           CY_CONV_AFFINE_ACT | flags, nullptr, nullptr, nullptr, scale, shift, act, res, ldres, s);
 }

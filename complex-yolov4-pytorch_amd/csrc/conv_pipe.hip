@@ -1,0 +1,526 @@
+// Pipelined implicit-GEMM convolution (forward and dgrad) for the 16-bit storage modes: the kernel the compute-bound
+// and the large HBM-bound layers of complex_yolov4.cfg run on (reference work unit: darknet2pytorch.py:247-278).
+//
+// Same GEMM view and the same gather scheme as conv_igemm.hip's fast path (D[co][pixel] = sum_k W[co][k] * X[pixel][k],
+// tap and channel offset wave-uniform per K step, out-of-range buffer offsets = zero fill), but built around what the
+// 2-barrier double buffer cannot do:
+//   * 512 threads = 8 waves (2 over channels x 4 over pixels), ONE block per CU, tile BN channels x BM pixels with
+//     BM = 256: 25 % fewer bytes through the CU's load path per MAC than two 128 x 128 blocks;
+//   * a 3-stage LDS ring filled by buffer_load ... lds with COUNTED s_waitcnt vmcnt(N) and a raw s_barrier: two K tiles
+//     stay in flight across every barrier (a __syncthreads() would drain the DMA queue each step);
+//   * v_mfma_f32_32x32x16 fragments (half the MFMA issue slots of 16x16x32, 2382 vs 2075 TF ubench ceiling);
+//   * LDS rows are 128 B (64 halfs), 16-byte chunk index XOR (row >> 1) & 7 -- applied on the DMA SOURCE side, the
+//     DMA image being lane-linear -- which is conflict-free for the 32-row ds_read_b128 fragment reads;
+//   * epilogue through LDS: every wave transposes its 64-channel x 64-pixel accumulator block to pixel-major rows and
+//     stores 16 B per lane, 128 contiguous bytes per pixel (the MFMA layout itself only yields 16-byte segments).
+// BatchNorm statistics, gradient fan-in (ACCUM), the eval-mode affine + activation (+ shortcut) epilogue and the
+// stride-2 dgrad parity classes behave exactly as in conv_igemm.hip (same IgemmParams, same stats table).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "igemm_common.hpp"
+
+namespace {
+using namespace cyk;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T>
+struct Mma32;
+template <>
+struct Mma32<f16> {
+    typedef f16x8 frag;
+    __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Mma32<bf16> {
+    typedef bf16x8 frag;
+    __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+// sum over the 32 lanes of a half wave that share lane >> 5 (every lane of the half ends up with the total)
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16, 64);
+}
+
+template <typename T, int BM, int BN, int WN, int NST, bool EPI_LDS>
+__global__ void __launch_bounds__(512, 2) igemm_pipe_kernel(const IgemmParams p) {
+    constexpr int WM = 8 / WN;                                // waves over channels x waves over pixels
+    constexpr int TI = BN / (32 * WN), TJ = BM / (32 * WM);   // 32 x 32 fragments per wave: channels, pixels
+    constexpr int XP = BM / 64, WP = BN / 64, NP = XP + WP;   // 1 KB DMA pieces per wave per K tile
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int BK = 64;
+    static_assert(BM % (32 * WM) == 0 && BM % 64 == 0 && BN % (32 * WN) == 0 && BN % 64 == 0 && NST >= 2 && NST <= 3, "tile / wave layout");
+    static_assert(NP <= 12, "vmcnt budget");
+    typedef typename Mma32<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* orow = reinterpret_cast<unsigned*>(smem + NST * STAGE);   // byte offset of every tile row's output pixel
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wm = wave / WN;
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tn = lid % p.ntiles, tm = lid / p.ntiles;
+
+    // ---- per-row gather table (one thread per tile row; the staging threads pick their rows up from LDS) -------------
+    const int ksign = p.transposed ? -1 : 1;
+    const int sh = (p.transposed && p.stride == 2) ? 1 : 0;
+    const int span = (p.ks - 1) >> sh;
+    const int dmin = p.transposed ? -(span * p.GW + span) * p.ldg * (int)sizeof(T) : 0;
+    const int ohw = p.OHc * p.OWc;
+    unsigned xoff[XP];
+    int ximask[XP];
+    {
+        uint2* rowinfo = reinterpret_cast<uint2*>(smem);
+        if (tid < BM) {
+            // the tile covers bm_eff <= BM pixels (the host sizes it so that the grid fills whole rounds of 256 CUs);
+            // rows beyond it gather zeros and store nothing
+            const int m = tm * p.bm_eff + tid;
+            unsigned base = 0u, mask = 0u, obyte = 0xFFFFFFFFu;
+            if (tid < p.bm_eff && m < p.M) {
+                const int n = m / ohw, rem = m - n * ohw;
+                const int ohc = rem / p.OWc;
+                const int oh = ohc * p.oh_mul + p.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
+                const int xh = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
+                const int xw = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
+                for (int t = 0; t < p.ntaps; ++t) {
+                    const int kh = (p.kh_pack >> (2 * t)) & 3, kw = (p.kw_pack >> (2 * t)) & 3;
+                    const int th = xh + ksign * kh, tw = xw + ksign * kw;
+                    const bool ok = (((th | tw) & sh) == 0) & ((unsigned)(th >> sh) < (unsigned)p.GH) &
+                                    ((unsigned)(tw >> sh) < (unsigned)p.GW);
+                    mask |= (ok ? 1u : 0u) << t;
+                }
+                base = (unsigned)(((n * p.GH + (xh >> sh)) * p.GW + (xw >> sh)) * p.ldg) * (unsigned)sizeof(T);
+                obyte = (unsigned)((n * p.OH + oh) * p.OW + ow) * (unsigned)p.ldo * (unsigned)sizeof(T);
+            }
+            rowinfo[tid] = make_uint2(base, mask);
+            orow[tid] = obyte;
+        }
+        __syncthreads();
+        // DMA lane l of a piece fills physical chunk l & 7 of row (l >> 3): it fetches logical chunk (l & 7) ^ f(row),
+        // f(row) = (row >> 1) & 7 = ((wave & 1) << 2) | (l >> 4) for the rows wave * 8 + 64 * i + (l >> 3) of this wave
+        const int chunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+        const unsigned lane_const = (unsigned)p.x_bias + (unsigned)dmin + (unsigned)(chunk * 16);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const uint2 ri = rowinfo[wave * 8 + (lane >> 3) + 64 * i];
+            xoff[i] = ri.x + lane_const;
+            ximask[i] = (int)~ri.y;
+        }
+        __syncthreads();   // stage 0 of the ring overlays rowinfo
+    }
+    unsigned woff[WP];
+    {
+        const int chunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            const int row = tn * BN + wave * 8 + (lane >> 3) + 64 * i;
+            woff[i] = row < p.wrows ? ((unsigned)row * (unsigned)p.K * (unsigned)sizeof(T) + (unsigned)(chunk * 16)) : 0xFFFFFFFFu;
+        }
+    }
+    const auto rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(p.g - p.x_bias), 0, p.g_bytes + p.x_bias, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // wave-uniform K position of the tile whose addresses are being prepared.  Tiles beyond the last one are "dummy":
+    // all their pieces carry out-of-range offsets (zero fill into a stage nobody reads any more), so every step issues
+    // exactly NP pieces -- one code path, one vmcnt count, no branches in the main loop.
+    int l_tap = 0, l_c = 0;
+    unsigned x_soff = 0u, w_soff = 0u, ld_oob = 0u;
+    int ld_tap = 0;
+    unsigned char* ld_dst = smem;
+    auto begin_tile = [&](int stage) {      // scalar part of a tile's addresses (SGPRs), then advance the K position
+        const bool real = l_tap < p.ntaps;
+        const int tsh = 2 * (real ? l_tap : 0);
+        const int kh = (p.kh_pack >> tsh) & 3, kw = (p.kw_pack >> tsh) & 3;
+        x_soff = (unsigned)((ksign * (((kh >> sh) * p.GW + (kw >> sh)) * p.ldg) + l_c) * (int)sizeof(T) - dmin);
+        w_soff = (unsigned)(((kh * p.ks + kw) * p.GC + l_c) * (int)sizeof(T));
+        ld_tap = real ? l_tap : 31;         // bit 31 of the inverted tap mask is always set -> every row out of range
+        ld_oob = real ? 0u : 0xFFFFFFFFu;
+        ld_dst = smem + stage * STAGE + wave * (8 * 128);
+        l_c += BK;
+        if (l_c >= p.GC) { l_c = 0; ++l_tap; }
+    };
+    auto issue_piece = [&](int pc) {        // pc: compile-time after unrolling
+        if (pc < XP) {
+            const unsigned v = xoff[pc] | (unsigned)(-((ximask[pc] >> ld_tap) & 1));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(ld_dst + pc * (64 * 128)), 16, v,
+                                                     x_soff, 0, 0);
+        } else {
+            const unsigned v = woff[pc - XP] | ld_oob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rs_w, (__attribute__((address_space(3))) void*)(ld_dst + BM * 128 + (pc - XP) * (64 * 128)), 16, v, w_soff, 0, 0);
+        }
+    };
+    auto issue_all = [&]() {
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) issue_piece(pc);
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment reads: lane l reads row (l & 31), logical chunk 2 s + (l >> 5) of K sub-step s -> physical chunk ^ (row >> 1) & 7
+    const int qx = ((lane >> 5) ^ ((lane >> 1) & 7)) << 4;
+    const int a_row = (BM + wn * (BN / WN) + (lane & 31)) * 128;
+    const int b_row = (wm * (BM / WM) + (lane & 31)) * 128;
+    frag a[2][TI], b[2][TJ];
+    auto load = [&](int set, int stage, int s) {
+        const unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) a[set][i] = *reinterpret_cast<const frag*>(sb + a_row + i * (32 * 128) + ((s * 32) ^ qx));
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) b[set][j] = *reinterpret_cast<const frag*>(sb + b_row + j * (32 * 128) + ((s * 32) ^ qx));
+    };
+    // the TI * TJ MFMAs of one K sub-step; with FIRST >= 0 the DMA pieces [FIRST, FIRST + COUNT) are issued between them
+    // (pinned with sched_barrier fences: hipcc otherwise re-clusters the independent MFMAs)
+    auto mma_sub = [&](int set, const int FIRST, const int COUNT) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                acc[i][j] = Mma32<T>::mma(a[set][i], b[set][j], acc[i][j]);
+                const int m = i * TJ + j;
+#pragma unroll
+                for (int k = 0; k < COUNT; ++k)
+                    if (FIRST >= 0 && k * (TI * TJ) / COUNT == m) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(FIRST + k);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+    };
+    // pieces of a tile spread over the 4 sub-steps of a K step: sub-step s issues [s * NP / 4, (s + 1) * NP / 4)
+    const int nkt = p.ntaps * (p.GC / BK);
+
+    if constexpr (NST == 3) {
+        // Top barrier.  Tile kt lives in stage kt % 3.  At the top of step kt this wave has tiles kt and kt + 1 in flight:
+        // waiting for vmcnt <= NP retires tile kt (in-order return); the barrier then (a) makes every wave's pieces of
+        // tile kt visible and (b) says every wave is done reading stage (kt + 2) % 3, which is refilled during this step.
+        // The scalar address part of the tile to issue is prepared at the END of the previous step, so that nothing but
+        // the first fragment reads sits between the barrier and the first MFMA.
+        begin_tile(0); issue_all();
+        begin_tile(1); issue_all();
+        begin_tile(2);
+        int cs = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            load(0, cs, 0);
+            load(1, cs, 1);
+            mma_sub(0, 0, NP / 4);
+            load(0, cs, 2);
+            mma_sub(1, NP / 4, NP / 2 - NP / 4);
+            load(1, cs, 3);
+            mma_sub(0, NP / 2, 3 * NP / 4 - NP / 2);
+            mma_sub(1, 3 * NP / 4, NP - 3 * NP / 4);
+            begin_tile(cs);              // tile kt + 3 -> the stage just consumed (issued during step kt + 1)
+            cs = cs == 2 ? 0 : cs + 1;
+        }
+    } else {
+        begin_tile(0); issue_all();
+        begin_tile(1);
+        for (int kt = 0; kt < nkt; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int cs = kt & 1;
+            load(0, cs, 0);
+            load(1, cs, 1);
+            mma_sub(0, 0, NP / 4);
+            load(0, cs, 2);
+            mma_sub(1, NP / 4, NP / 2 - NP / 4);
+            load(1, cs, 3);
+            mma_sub(0, NP / 2, 3 * NP / 4 - NP / 2);
+            mma_sub(1, 3 * NP / 4, NP - 3 * NP / 4);
+            begin_tile(cs);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tiles' zero fills must not land on the epilogue's LDS use
+    __syncthreads();   // every wave is done with the ring: the epilogue reuses it
+
+    // ---- epilogue -----------------------------------------------------------------------------------------------------
+    // lane holds D[co = cw + i*32 + 8*g + 4*(lane>>5) + r][pixel row = pw + j*32 + (lane&31)], acc register 4*g + r
+    const int half = lane >> 5;
+    const int cw = wn * (BN / WN);         // first channel of this wave inside the tile
+    const int pw = wm * (BM / WM);         // first pixel row of this wave inside the tile
+    const int co_w = tn * BN + cw;
+
+    if (p.flags & CY_CONV_STATS) {
+        float* red = reinterpret_cast<float*>(smem);        // [WM][2][BN]
+        bool rowok[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) rowok[j] = orow[pw + j * 32 + (lane & 31)] != 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const float v = rowok[j] ? acc[i][j][t] : 0.f;
+                    s += v;
+                    q += v * v;
+                }
+                s = half32_sum(s);
+                q = half32_sum(q);
+                if ((lane & 31) == t) { sv = s; qv = q; }
+            }
+            if ((lane & 31) < 16) {     // lane t of each half publishes accumulator register t = 4 g + r
+                const int t = lane & 31;
+                const int cl = cw + i * 32 + 8 * (t >> 2) + 4 * half + (t & 3);
+                red[(wm * 2 + 0) * BN + cl] = sv;
+                red[(wm * 2 + 1) * BN + cl] = qv;
+            }
+        }
+        __syncthreads();
+        float* srow = p.stats + (size_t)(p.stat_rows == 64 ? (lid & 63) : tm) * 2 * p.OC;
+        for (int c = tid; c < 2 * BN; c += 512) {
+            const int mom = c / BN, cl = c - mom * BN, co = tn * BN + cl;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[(2 * w + mom) * BN + cl];
+            if (co < p.OC) atomicAdd(srow + mom * p.OC + co, t);
+        }
+        __syncthreads();
+    }
+
+    if (p.flags & CY_CONV_AFFINE_ACT) {
+        typedef T rx4 __attribute__((ext_vector_type(4)));
+        const T* resrow[TJ];     // the shortcut operand has the output's pixel indexing (its own channel stride)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const unsigned ob = orow[pw + j * 32 + (lane & 31)];
+            resrow[j] = (p.res && ob != 0xFFFFFFFFu)
+                            ? reinterpret_cast<const T*>(p.res) + (size_t)(ob / ((unsigned)p.ldo * (unsigned)sizeof(T))) * p.ldres
+                            : nullptr;
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co_w + i * 32 + 8 * g + 4 * half;
+                float sc[4], sf[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = min(co + r, p.OC - 1);
+                    sc[r] = p.aff_scale[c];
+                    sf[r] = p.aff_shift[c];
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = acc[i][j][4 * g + r] * sc[r] + sf[r];
+                        const float zm = mish_f<true>(z), zl = z > 0.f ? z : 0.1f * z;
+                        acc[i][j][4 * g + r] = p.act == CY_ACT_MISH ? zm : (p.act == CY_ACT_LEAKY ? zl : z);   // selects, no branches
+                    }
+                    if (resrow[j] && co + 3 < p.OC) {
+                        const rx4 rv = *reinterpret_cast<const rx4*>(resrow[j] + co);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][4 * g + r] += (float)rv[r];
+                    }
+                }
+            }
+    }
+
+    const bool accum = (p.flags & CY_CONV_ACCUM) != 0;
+    typedef T tx4 __attribute__((ext_vector_type(4)));
+    typedef T tx8 __attribute__((ext_vector_type(8)));
+    if constexpr (EPI_LDS) {
+        // wave-private [BM/WM pixel rows][BN/WN channels] tile, 16-byte chunk index XOR (row & 7)
+        constexpr int ROWB = (BN / WN) * 2;      // bytes per pixel row of the wave tile (128 for 64 channels)
+        constexpr int CPR = ROWB / 16;           // 16-byte chunks per row
+        constexpr int WROWS = BM / WM;
+        unsigned char* wt = smem + wave * (WROWS * ROWB);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    tx4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (T)acc[i][j][4 * g + r];
+                    const int row = j * 32 + (lane & 31);
+                    const int ck = (i * 4 + g) ^ (row & (CPR - 1) & 7);
+                    *reinterpret_cast<tx4*>(wt + row * ROWB + ck * 16 + half * 8) = h;
+                }
+        // (wave-private: the wave's own ds_writes are ordered before its ds_reads by lgkmcnt, no barrier needed)
+        constexpr int RPI = 64 / CPR;            // pixel rows per store instruction
+#pragma unroll
+        for (int t = 0; t < WROWS / RPI; ++t) {
+            const int row = t * RPI + lane / CPR, c = lane % CPR;
+            const unsigned ob = orow[pw + row];
+            const int co = co_w + c * 8;
+            const tx8 v = *reinterpret_cast<const tx8*>(wt + row * ROWB + ((c ^ (row & (CPR - 1) & 7)) * 16));
+            if (ob == 0xFFFFFFFFu || co >= p.OC) continue;
+            T* dst = reinterpret_cast<T*>(p.o + ob) + co;
+            if (co + 8 <= p.OC) {
+                tx8 o = v;
+                if (accum) {
+                    const tx8 old = *reinterpret_cast<const tx8*>(dst);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (T)((float)v[e] + (float)old[e]);
+                }
+                *reinterpret_cast<tx8*>(dst) = o;
+            } else {
+                for (int e = 0; e < 8 && co + e < p.OC; ++e) dst[e] = (T)((float)v[e] + (accum ? (float)dst[e] : 0.f));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const unsigned ob = orow[pw + j * 32 + (lane & 31)];
+            if (ob == 0xFFFFFFFFu) continue;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = co_w + i * 32 + 8 * g + 4 * half;
+                    if (co >= p.OC) continue;
+                    T* dst = reinterpret_cast<T*>(p.o + ob) + co;
+                    if (co + 3 < p.OC) {
+                        tx4 h;
+                        if (accum) {
+                            const tx4 old = *reinterpret_cast<const tx4*>(dst);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) h[r] = (T)(acc[i][j][4 * g + r] + (float)old[r]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) h[r] = (T)acc[i][j][4 * g + r];
+                        }
+                        *reinterpret_cast<tx4*>(dst) = h;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co + r < p.OC) dst[r] = (T)(acc[i][j][4 * g + r] + (accum ? (float)dst[r] : 0.f));
+                    }
+                }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WN, int NST, bool EPI_LDS>
+int pipe_launch(const IgemmParams& p0, hipStream_t s) {
+    IgemmParams p = p0;
+    p.mtiles = (p.M + p.bm_eff - 1) / p.bm_eff;
+    p.ntiles = (p.OC + BN - 1) / BN;
+    constexpr int smem = NST * (BM + BN) * 128 + BM * 4;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<T, BM, BN, WN, NST, EPI_LDS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((igemm_pipe_kernel<T, BM, BN, WN, NST, EPI_LDS>), dim3(p.mtiles * p.ntiles), dim3(512), smem, s, p);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+// tile capacities: 384 / 256 / 128 pixels = 4 waves over pixels x 2 over channels, 192 = 2 x 4 (BN = 128 only);
+// a 384-pixel tile leaves room for a 2-stage ring only.  variant: 0 shipped, 1 direct stores, 2 two-stage ring,
+// 3 DMA pieces issued as a burst behind the barrier instead of between the MFMAs, 5 barrier before the last sub-step
+// of a K step instead of at its top, 6 ping-pong phases (two wave groups one barrier apart).
+template <typename T>
+int pipe_dispatch(const IgemmParams& p, int cap, int bn, int variant, hipStream_t s) {
+#define CY_PIPE(BM_, BN_, WN_, NST_)                                                           \
+    if (cap == BM_ && bn == BN_) {                                                             \
+        if (variant == 1 || (p.flags & CY_CONV_ACCUM)) return pipe_launch<T, BM_, BN_, WN_, NST_, false>(p, s); \
+        if (variant == 2) return pipe_launch<T, BM_, BN_, WN_, 2, true>(p, s);                                \
+        return pipe_launch<T, BM_, BN_, WN_, NST_, true>(p, s);                                               \
+    }
+    CY_PIPE(384, 128, 2, 2) CY_PIPE(256, 128, 2, 3) CY_PIPE(192, 128, 4, 3) CY_PIPE(128, 128, 2, 3)
+    CY_PIPE(384, 64, 2, 2) CY_PIPE(256, 64, 2, 3) CY_PIPE(128, 64, 2, 3)
+#undef CY_PIPE
+    return CY_ERR_ARG;
+}
+
+}  // namespace
+
+static int64_t g_pipe_launches = 0;
+static int g_pipe_mode = -1, g_pipe_cap = 0, g_pipe_bn = 0, g_pipe_variant = 0, g_pipe_bm_eff = 0;
+
+extern "C" int64_t cy_pipe_launches(void) { return g_pipe_launches; }
+
+extern "C" int cy_conv_pipe_config(int mode, int cap, int bn, int variant, int bm_eff) {
+    g_pipe_mode = mode; g_pipe_cap = cap; g_pipe_bn = bn; g_pipe_variant = variant; g_pipe_bm_eff = bm_eff;
+    return 0;
+}
+
+// Tile policy.  One block per CU, so the grid runs in rounds of 256 tiles and a tile costs ~ (capacity + fixed) whatever
+// part of it holds real pixels: for every capacity take the rounds it needs, spread the pixels evenly over the pixel
+// tiles that fit those rounds (bm_eff <= capacity), and keep the cheapest (rounds x tile cost).  only_cap != 0 restricts
+// the choice to that capacity (the engine's per-layer autotuner names capacities through the CY_CONV_TILE flag field).
+static bool pipe_policy(int M, int OC, int only_cap, int& cap, int& bn, int& bm_eff) {
+    bn = OC > 64 ? 128 : 64;
+    const int ntiles = (OC + bn - 1) / bn;
+    static const int caps128[] = {128, 192, 256, 384}, caps64[] = {128, 256, 384};
+    const int* caps = bn == 128 ? caps128 : caps64;
+    const int ncaps = bn == 128 ? 4 : 3;
+    const double fixed = 96.0;      // prologue + epilogue + pipeline fill of one tile, in pixel-equivalents of main loop
+    double best = 1e30;
+    bool found = false;
+    for (int c = 0; c < ncaps; ++c) {
+        if (only_cap && caps[c] != only_cap) continue;
+        const long tiles = (long)((M + caps[c] - 1) / caps[c]) * ntiles;
+        const long r = (tiles + 255) / 256;                 // rounds this capacity needs
+        const long mt = 256 * r / ntiles;                   // pixel tiles that fit those rounds
+        int eff = (int)((M + mt - 1) / mt);                 // spread the pixels evenly over them
+        if (eff < 64) eff = 64;
+        if (eff > caps[c]) eff = caps[c];
+        const double cost = r * (caps[c] * (caps[c] == 384 ? 1.08 : 1.0) + fixed);   // 384: 2-stage ring only
+        if (cost < best) { best = cost; cap = caps[c]; bm_eff = eff; found = true; }
+    }
+    return found;
+}
+
+// Launches the pipelined kernel when the shape qualifies (*used = 1), else leaves the launch to conv_igemm.hip.
+// Which launches take it: the CY_CONV_TILE hint of the call (1: never, 2-5: capacity 128 / 192 / 256 / 384, 6: policy
+// tile); without a hint the eval-mode epilogue always does (its LDS-transposed stores are worth 1.3-2x on every shape of
+// complex_yolov4.cfg), training launches stay on the 4-wave kernels: measured per layer the two families are within
+// +-10 % of each other with the winner depending on how the tiles quantise over 256 CUs, so the engine times both once
+// per layer shape and passes the hint (models/engine.py).
+int cy_pipe_try(const cyk::IgemmParams& p0, int dtype, hipStream_t s, int* used) {
+    *used = 0;
+    if (g_pipe_mode < 0) {
+        const char* e = getenv("CY_CONV_PIPE");
+        g_pipe_mode = e ? atoi(e) : 1;
+    }
+    const int hint = (p0.flags >> CY_CONV_TILE_SHIFT) & 15;
+    if (g_pipe_mode == 0 || hint == 1 || (dtype != CY_F16 && dtype != CY_BF16)) return 0;
+    if (g_pipe_mode == 1 && hint == 0 && !(p0.flags & CY_CONV_AFFINE_ACT)) return 0;
+    if (p0.GC % 64 || !p0.x_bias || (p0.flags & CY_CONV_BIAS_F32OUT) || p0.OC % 8 || p0.ldo % 8) return 0;
+    if (((uintptr_t)p0.o & 15) || (p0.res && (p0.ldres % 4 || ((uintptr_t)p0.res & 7)))) return 0;
+    if ((size_t)p0.N * p0.OH * p0.OW * p0.ldo * 2 >= 0xFFFFFF00ull) return 0;      // 32-bit output row offsets
+    cyk::IgemmParams p = p0;
+    static const int hint_cap[] = {0, 0, 128, 192, 256, 384, 0};
+    int only = hint >= 2 && hint <= 5 ? hint_cap[hint] : 0;
+    if (only == 192 && p.OC <= 64) only = 256;
+    int cap = 0, bn = 0, eff = 0;
+    if (!pipe_policy(p.M, p.OC, only, cap, bn, eff)) return 0;
+    if (g_pipe_cap) { cap = g_pipe_cap; bn = g_pipe_bn; eff = g_pipe_bm_eff ? g_pipe_bm_eff : cap; }
+    if (eff > cap) return CY_ERR_ARG;
+    p.bm_eff = eff;
+    if (p.stat_rows != 64) p.stat_rows = (p.M + eff - 1) / eff;    // deterministic statistics: one table row per pixel tile
+    const int rc = dtype == CY_F16 ? pipe_dispatch<f16>(p, cap, bn, g_pipe_variant, s) : pipe_dispatch<bf16>(p, cap, bn, g_pipe_variant, s);
+    if (rc == 0) { *used = 1; ++g_pipe_launches; }
+    return rc;
+}

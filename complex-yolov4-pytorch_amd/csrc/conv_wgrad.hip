@@ -37,9 +37,36 @@ struct WTraits<f16> {
     static constexpr int BKP = 64;
 };
 template <>
+struct WTraits<bf16> {
+    static constexpr int BKP = 64;
+};
+template <>
 struct WTraits<float> {
     static constexpr int BKP = 32;
 };
+
+// 16-bit MFMA on 8-element fragments of either storage type; the transpose read is type-blind (16-bit elements)
+template <typename T>
+struct WMma;
+template <>
+struct WMma<f16> {
+    typedef f16x8 frag;
+    __device__ static __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct WMma<bf16> {
+    typedef bf16x8 frag;
+    __device__ static __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <typename T>
+__device__ __forceinline__ typename WMma<T>::frag tr16_pair(const unsigned char* lo_ptr, const unsigned char* hi_ptr) {
+    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(lo_ptr));
+    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(hi_ptr));
+    u32x4 v;
+    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+    v[0] = l[0]; v[1] = l[1]; v[2] = h[0]; v[3] = h[1];
+    return __builtin_bit_cast(typename WMma<T>::frag, v);
+}
 
 template <typename T, int BCO, int BCI, bool USE_TR>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
@@ -145,7 +172,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int kk = 0; kk < BKP / 32; ++kk) {
-                f16x8 a[TI], b[TJ];
+                typename WMma<T>::frag a[TI], b[TJ];
                 if constexpr (USE_TR) {
                     // lane supplies row (q16>>2) and 4 channels at (q16&3)*4 of a [4 pixel][16 channel] block;
                     // it receives channel q16 of the 4 pixel rows (hardware transpose within 16 lanes).
@@ -153,22 +180,12 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 #pragma unroll
                     for (int i = 0; i < TI; ++i) {
                         const unsigned char* ptr = as + prow * RB_A + ((wi * (BCO / 2) + i * 16 + ((q16 & 3) << 2)) << 1);
-                        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                            (__attribute__((address_space(3))) fp16x4_t*)(ptr));
-                        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                            (__attribute__((address_space(3))) fp16x4_t*)(ptr + 4 * RB_A));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { a[i][e] = (f16)lo[e]; a[i][4 + e] = (f16)hi[e]; }
+                        a[i] = tr16_pair<T>(ptr, ptr + 4 * RB_A);
                     }
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) {
                         const unsigned char* ptr = bs + prow * RB_B + ((wj * (BCI / 2) + j * 16 + ((q16 & 3) << 2)) << 1);
-                        const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                            (__attribute__((address_space(3))) fp16x4_t*)(ptr));
-                        const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                            (__attribute__((address_space(3))) fp16x4_t*)(ptr + 4 * RB_B));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { b[j][e] = (f16)lo[e]; b[j][4 + e] = (f16)hi[e]; }
+                        b[j] = tr16_pair<T>(ptr, ptr + 4 * RB_B);
                     }
                 } else {
                     const int prow = kk * 32 + g * 8;
@@ -176,18 +193,18 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
                     for (int i = 0; i < TI; ++i)
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            a[i][e] = *reinterpret_cast<const f16*>(as + (prow + e) * RB_A + ((wi * (BCO / 2) + i * 16 + q16) << 1));
+                            a[i][e] = *reinterpret_cast<const T*>(as + (prow + e) * RB_A + ((wi * (BCO / 2) + i * 16 + q16) << 1));
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            b[j][e] = *reinterpret_cast<const f16*>(bs + (prow + e) * RB_B + ((wj * (BCI / 2) + j * 16 + q16) << 1));
+                            b[j][e] = *reinterpret_cast<const T*>(bs + (prow + e) * RB_B + ((wj * (BCI / 2) + j * 16 + q16) << 1));
                 }
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = WMma<T>::mma(a[i], b[j], acc[i][j]);
             }
         } else {
 #pragma unroll
@@ -250,7 +267,7 @@ __device__ __forceinline__ int wg_key(int row) {
     else return (row >> 3) & 1;
 }
 
-template <int BCO, int BCI>
+template <typename T, int BCO, int BCI>
 __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) {
     constexpr int BKP = 64;
     constexpr int RBA = BCO * 2, RBB = BCI * 2;          // row bytes
@@ -372,27 +389,21 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
         const unsigned char* st = smem + cur * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BKP / 32; ++kk) {
-            f16x8 a[TI], b[TJ];
+            typename WMma<T>::frag a[TI], b[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const unsigned char* ptr = st + a_col[i] + kk * 32 * RBA;
-                const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr));
-                const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr + 4 * RBA));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a[i][e] = (f16)lo[e]; a[i][4 + e] = (f16)hi[e]; }
+                a[i] = tr16_pair<T>(ptr, ptr + 4 * RBA);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const unsigned char* ptr = st + b_col[j] + kk * 32 * RBB;
-                const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr));
-                const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr + 4 * RBB));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { b[j][e] = (f16)lo[e]; b[j][4 + e] = (f16)hi[e]; }
+                b[j] = tr16_pair<T>(ptr, ptr + 4 * RBB);
             }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = WMma<T>::mma(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
@@ -412,19 +423,19 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
         }
 }
 
-template <int BCO, int BCI>
+template <typename T, int BCO, int BCI>
 int launch_dma(const WgradParams& p, int split, hipStream_t s) {
     constexpr int smem = 2 * 64 * (BCO * 2 + BCI * 2);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<BCO, BCI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, BCO, BCI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     WgradParams q = p;
     q.ncol_tiles = (p.Ncols + BCI - 1) / BCI;
     q.nco_tiles = (p.CoRows + BCO - 1) / BCO;
-    hipLaunchKernelGGL((wgrad_dma_kernel<BCO, BCI>), dim3(q.ncol_tiles * q.nco_tiles * split), dim3(256), smem, s, q);
+    hipLaunchKernelGGL((wgrad_dma_kernel<T, BCO, BCI>), dim3(q.ncol_tiles * q.nco_tiles * split), dim3(256), smem, s, q);
     CY_LAUNCH_CHECK();
     return 0;
 }
@@ -449,10 +460,11 @@ int launch(const WgradParams& p, int split, hipStream_t s) {
 
 inline int tile_of(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
 
-inline int dispatch_dma(const WgradParams& p, int split, hipStream_t s) {
+template <typename T>
+int dispatch_dma(const WgradParams& p, int split, hipStream_t s) {
     const int bco = tile_of(p.CoRows), bci = tile_of(p.Ncols);
 #define CY_WD(A, B) \
-    if (bco == A && bci == B) return launch_dma<A, B>(p, split, s);
+    if (bco == A && bci == B) return launch_dma<T, A, B>(p, split, s);
     CY_WD(128, 128) CY_WD(128, 64) CY_WD(128, 32) CY_WD(64, 128) CY_WD(64, 64) CY_WD(64, 32) CY_WD(32, 128) CY_WD(32, 64)
     CY_WD(32, 32)
 #undef CY_WD
@@ -555,15 +567,8 @@ extern "C" int cy_conv_wgrad_split(int M, int Co, int Ci, int ks) {
     CY_ENTER();
     const int ncols = ks * ks * Ci;
     const long tiles = (long)((Co + tile_of(Co) - 1) / tile_of(Co)) * ((ncols + tile_of(ncols) - 1) / tile_of(ncols));
-    static long target = -1, minpix = -1;
-    if (target < 0) {
-        const char* e = getenv("CY_WGRAD_BLOCKS");
-        target = e ? atol(e) : 768;
-        const char* f = getenv("CY_WGRAD_MINPIX");
-        minpix = f ? atol(f) : 512;
-    }
+    const long target = 768, minpix = 512;   // ~3 blocks per CU; at least minpix / 64 K steps per block (the engine then times the neighbours)
     long split = (target + tiles - 1) / tiles;
-    if (const char* fs = getenv("CY_WGRAD_SPLIT")) split = atol(fs);   // experiments: force the split
     const long max_by_work = (M + minpix - 1) / minpix;  // at least minpix/64 K steps per block
     if (split > max_by_work) split = max_by_work;
     const long slab = (long)Co * ncols * 4;
@@ -575,26 +580,26 @@ extern "C" int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int 
                              int Ci, int ldx, int ks, int stride, int pad, int dtype, float* part, int split,
                              int use_tr, cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
-    if (!dy || !x || !part || split < 1 || (dtype != CY_F16 && dtype != CY_F32)) return CY_ERR_ARG;
+    const int ch = dtype == CY_F32 ? 4 : 8;
+    if (!dy || !x || !part || split < 1 || (dtype != CY_F16 && dtype != CY_BF16 && dtype != CY_F32)) return CY_ERR_ARG;
     if (Co % ch || Ci % ch || lddy % ch || ldx % ch || ks < 1 || ks > 3) return CY_ERR_ARG;
     WgradParams p;
     p.dy = (const unsigned char*)dy; p.x = (const unsigned char*)x; p.part = part;
     p.N = N; p.OH = OH; p.OW = OW; p.Co = Co; p.lddy = lddy;
     p.XH = XH; p.XW = XW; p.Ci = Ci; p.ldx = ldx; p.ks = ks; p.stride = stride; p.pad = pad;
     p.M = N * OH * OW; p.Ncols = ks * ks * Ci; p.CoRows = Co;
-    const int bkp = dtype == CY_F16 ? 64 : 32;
+    const int bkp = dtype == CY_F32 ? 32 : 64;
     p.pps = (((p.M + split - 1) / split) + bkp - 1) / bkp * bkp;
     p.x_bytes = 0;
     if (dtype == CY_F32) return dispatch<float, false>(p, split, cy_s(s));
-    {   // direct-to-LDS kernel (CY_WGRAD_DMA=0: register-staged kernel, A/B runs; use_tr = 2 forces the staged kernel too)
-        const char* e = getenv("CY_WGRAD_DMA");
+    {   // direct-to-LDS kernel; use_tr = 2 forces the register-staged kernel (A/B runs), as do offsets beyond 32 bits
         const size_t xb = (((size_t)N * XH * XW - 1) * ldx + Ci) * 2, ab = ((size_t)p.M + 128) * lddy * 2;
-        if (use_tr == 1 && !(e && !atoi(e)) && xb < 0xFFFFFF00ull && ab < 0xFFFFFF00ull && 64 / OW + 1 <= 2 * OH) {
+        if (use_tr == 1 && xb < 0xFFFFFF00ull && ab < 0xFFFFFF00ull && 64 / OW + 1 <= 2 * OH) {
             p.x_bytes = (unsigned)xb;
-            return dispatch_dma(p, split, cy_s(s));
+            return dtype == CY_F16 ? dispatch_dma<f16>(p, split, cy_s(s)) : dispatch_dma<bf16>(p, split, cy_s(s));
         }
     }
+    if (dtype == CY_BF16) return use_tr ? dispatch<bf16, true>(p, split, cy_s(s)) : dispatch<bf16, false>(p, split, cy_s(s));
     return use_tr ? dispatch<f16, true>(p, split, cy_s(s)) : dispatch<f16, false>(p, split, cy_s(s));
 }
 

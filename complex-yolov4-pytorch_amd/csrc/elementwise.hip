@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int ppb,
-                                                           float* __restrict__ part) {
+                                                           float* __restrict__ part, int det) {
     constexpr int CH = Elem<T>::CH;
     __shared__ float red[256 * CH * 2];
     const int cpr = C / CH, rpp = 256 / cpr;
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
         const int i = o % CH, which = (o / CH) & 1, ck = o / (2 * CH);
         float s = 0.f;
         for (int r = 0; r < rpp; ++r) s += red[((r * cpr + ck) * 2 + which) * CH + i];
-        atomicAdd(&part[((size_t)(blockIdx.x & 63) * 2 + which) * C + ck * CH + i], s);
+        atomicAdd(&part[((size_t)(det ? blockIdx.x : (blockIdx.x & 63)) * 2 + which) * C + ck * CH + i], s);
     }
 }
 
@@ -140,17 +140,23 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
 // finish: one wave per channel, lane k owns bin k of the [64][2][C] fp32 table (filled with atomics by the conv
 // epilogue / the backward reduce); the lane that read a bin zeroes it, so the table is clean for its next user.
 constexpr int CY_BINS = 64;
-__global__ void __launch_bounds__(256) bn_finalize_kernel(float* __restrict__ bins, int C, double count,
+__global__ void __launch_bounds__(256) bn_finalize_kernel(float* __restrict__ bins, int rows, int C, double count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* rmean, float* rvar, long long* nbt, float momentum,
                                                          float eps, float* mean, float* invstd, float* scale, float* shift) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    float* p0 = bins + ((size_t)lane * 2) * C + c;
-    float* p1 = bins + ((size_t)lane * 2 + 1) * C + c;
-    double s = (double)*p0, q = (double)*p1;
-    *p0 = 0.f;
-    *p1 = 0.f;
+    // lane k folds rows k, k + 64, ... in that order, then a fixed butterfly over the lanes: the result does not depend
+    // on which block produced which row when (the deterministic mode has one row per pixel tile)
+    double s = 0.0, q = 0.0;
+    for (int r = lane; r < rows; r += 64) {
+        float* p0 = bins + ((size_t)r * 2) * C + c;
+        float* p1 = bins + ((size_t)r * 2 + 1) * C + c;
+        s += (double)*p0;
+        q += (double)*p1;
+        *p0 = 0.f;
+        *p1 = 0.f;
+    }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
     if (lane != 0) return;
@@ -180,15 +186,19 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(float* __restrict__ bins, int C, float* dgs, float* dbs,
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(float* __restrict__ bins, int rows, int C, float* dgs, float* dbs,
                                                              float* ggamma, float* gbeta, float gscale) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    float* p0 = bins + ((size_t)lane * 2) * C + c;
-    float* p1 = bins + ((size_t)lane * 2 + 1) * C + c;
-    double s1 = (double)*p0, s2 = (double)*p1;
-    *p0 = 0.f;
-    *p1 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = lane; r < rows; r += 64) {
+        float* p0 = bins + ((size_t)r * 2) * C + c;
+        float* p1 = bins + ((size_t)r * 2 + 1) * C + c;
+        s1 += (double)*p0;
+        s2 += (double)*p1;
+        *p0 = 0.f;
+        *p1 = 0.f;
+    }
     s1 = wave_sum_d(s1);
     s2 = wave_sum_d(s2);
     if (lane != 0) return;
@@ -656,13 +666,14 @@ inline int ppb_for(long M, int C, int ch) {
 
 }  // namespace
 
-#define CY_DT_SWITCH(dtype, EXPR_F16, EXPR_F32) \
-    if (dtype == CY_F16) { EXPR_F16; } else if (dtype == CY_F32) { EXPR_F32; } else return CY_ERR_ARG;
+#define CY_DT_SWITCH(dtype, M)                                                                       \
+    if (dtype == CY_F16) { M(f16) } else if (dtype == CY_BF16) { M(bf16) } else if (dtype == CY_F32) { M(float) } \
+    else return CY_ERR_ARG;
 
 extern "C" int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
                              const float* scale, const float* shift, int act, int dtype, cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!x || !y || !scale || !shift || !rowmap_ok(C, ch) || ldx % ch || ldy % ch || (res && ldres % ch)) return CY_ERR_ARG;
     const int ppb = ppb_for(M, C, ch);
     const dim3 grid((unsigned)((M + ppb - 1) / ppb));
@@ -675,7 +686,7 @@ extern "C" int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const voi
     if (act == CY_ACT_MISH) { CY_BNF(T, CY_ACT_MISH) }       \
     else if (act == CY_ACT_LEAKY) { CY_BNF(T, CY_ACT_LEAKY) } \
     else { CY_BNF(T, CY_ACT_LINEAR) }
-    CY_DT_SWITCH(dtype, CY_BNF_ACT(f16), CY_BNF_ACT(float))
+    CY_DT_SWITCH(dtype, CY_BNF_ACT)
 #undef CY_BNF
 #undef CY_BNF_ACT
     CY_LAUNCH_CHECK();
@@ -686,28 +697,38 @@ extern "C" int cy_bn_scratch_rows(void) { return 0; }
 
 extern "C" int cy_bn_bwd_rows(int64_t M, int C, int dtype) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!rowmap_ok(C, ch)) return CY_ERR_ARG;
     (void)M;
     return CY_BINS;
 }
 
+extern "C" int cy_bn_bwd_rows_det(int64_t M, int C, int dtype) {
+    CY_ENTER();
+    const int ch = dtype == CY_F32 ? 4 : 8;
+    if (!rowmap_ok(C, ch)) return CY_ERR_ARG;
+    const int ppb = ppb_for(M, C, ch);
+    return (int)((M + ppb - 1) / ppb);
+}
+
 extern "C" int cy_bn_act_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, int64_t M, int C,
                                     const float* mean, const float* invstd, const float* scale, const float* shift,
-                                    int act, int dtype, float* part, cy_stream_t s) {
+                                    int act, int dtype, float* part, int rows, cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!x || !dy || !part || !rowmap_ok(C, ch) || ldx % ch || lddy % ch) return CY_ERR_ARG;
     const int ppb = ppb_for(M, C, ch);
     const dim3 grid((unsigned)((M + ppb - 1) / ppb));
+    if (rows != CY_BINS && rows != (int)grid.x) return CY_ERR_ARG;
+    const int det = rows != CY_BINS;
 #define CY_BNR(T, A)                                                                                            \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, A>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (const T*)dy, \
-                       lddy, (long)M, C, mean, invstd, scale, shift, ppb, part);
+                       lddy, (long)M, C, mean, invstd, scale, shift, ppb, part, det);
 #define CY_BNR_ACT(T)                                        \
     if (act == CY_ACT_MISH) { CY_BNR(T, CY_ACT_MISH) }       \
     else if (act == CY_ACT_LEAKY) { CY_BNR(T, CY_ACT_LEAKY) } \
     else { CY_BNR(T, CY_ACT_LINEAR) }
-    CY_DT_SWITCH(dtype, CY_BNR_ACT(f16), CY_BNR_ACT(float))
+    CY_DT_SWITCH(dtype, CY_BNR_ACT)
 #undef CY_BNR
 #undef CY_BNR_ACT
     CY_LAUNCH_CHECK();
@@ -720,7 +741,7 @@ extern "C" int cy_bn_act_bwd_apply(const void* x, int ldx, const void* dy, int l
                                    const float* dgamma_sum, const float* dbeta_sum, int act, int dtype,
                                    cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!x || !dy || !dx || !rowmap_ok(C, ch) || ldx % ch || lddy % ch || lddx % ch || (res_grad && ldrg % ch))
         return CY_ERR_ARG;
     const int ppb = ppb_for(M, C, ch);
@@ -733,7 +754,7 @@ extern "C" int cy_bn_act_bwd_apply(const void* x, int ldx, const void* dy, int l
     if (act == CY_ACT_MISH) { CY_BNA(T, CY_ACT_MISH) }       \
     else if (act == CY_ACT_LEAKY) { CY_BNA(T, CY_ACT_LEAKY) } \
     else { CY_BNA(T, CY_ACT_LINEAR) }
-    CY_DT_SWITCH(dtype, CY_BNA_ACT(f16), CY_BNA_ACT(float))
+    CY_DT_SWITCH(dtype, CY_BNA_ACT)
 #undef CY_BNA
 #undef CY_BNA_ACT
     CY_LAUNCH_CHECK();
@@ -747,8 +768,7 @@ extern "C" int cy_bn_finalize(const float* stats_part, int rows, int C, int64_t 
     CY_ENTER();
     if (!stats_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows < 1 || count < 1)
         return CY_ERR_ARG;
-    if (rows != CY_BINS) return CY_ERR_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), const_cast<float*>(stats_part), C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), const_cast<float*>(stats_part), rows, C,
                        (double)count, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum,
                        eps, mean, invstd, scale, shift);
     CY_LAUNCH_CHECK();
@@ -770,8 +790,7 @@ extern "C" int cy_bn_bwd_finalize(const float* part, int rows, int C, float* dga
                                   float* ggamma, float* gbeta, float gscale, cy_stream_t s) {
     CY_ENTER();
     if (!part || !dgamma_sum || !dbeta_sum || rows < 1) return CY_ERR_ARG;
-    if (rows != CY_BINS) return CY_ERR_ARG;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), const_cast<float*>(part), C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, cy_s(s), const_cast<float*>(part), rows, C,
                        dgamma_sum, dbeta_sum, ggamma, gbeta, gscale);
     CY_LAUNCH_CHECK();
     return 0;
@@ -780,7 +799,7 @@ extern "C" int cy_bn_bwd_finalize(const float* part, int rows, int C, float* dga
 extern "C" int cy_slice_copy(const void* x, int ldx, void* y, int ldy, int64_t M, int C, int accumulate, int dtype,
                              cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!x || !y || C % ch || ldx % ch || ldy % ch) return CY_ERR_ARG;
     const int g = grid_for(M * (C / ch));
 #define CY_SL(T)                                                                                                     \
@@ -788,7 +807,7 @@ extern "C" int cy_slice_copy(const void* x, int ldx, void* y, int ldy, int64_t M
                                        (const T*)nullptr, 0, (T*)y, ldy, (long)M, C);                                \
     else hipLaunchKernelGGL((slice_kernel<T, 0>), dim3(g), dim3(256), 0, cy_s(s), (const T*)x, ldx, (const T*)nullptr, \
                             0, (T*)y, ldy, (long)M, C);
-    CY_DT_SWITCH(dtype, CY_SL(f16), CY_SL(float))
+    CY_DT_SWITCH(dtype, CY_SL)
 #undef CY_SL
     CY_LAUNCH_CHECK();
     return 0;
@@ -797,13 +816,13 @@ extern "C" int cy_slice_copy(const void* x, int ldx, void* y, int ldy, int64_t M
 extern "C" int cy_slice_add(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int64_t M, int C,
                             int dtype, cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!a || !b || !y || C % ch || lda % ch || ldb % ch || ldy % ch) return CY_ERR_ARG;
     const int g = grid_for(M * (C / ch));
 #define CY_SA(T) \
     hipLaunchKernelGGL((slice_kernel<T, 2>), dim3(g), dim3(256), 0, cy_s(s), (const T*)a, lda, (const T*)b, ldb, (T*)y, \
                        ldy, (long)M, C);
-    CY_DT_SWITCH(dtype, CY_SA(f16), CY_SA(float))
+    CY_DT_SWITCH(dtype, CY_SA)
 #undef CY_SA
     CY_LAUNCH_CHECK();
     return 0;
@@ -814,7 +833,7 @@ extern "C" int64_t cy_maxpool_argmax_bytes(int N, int H, int OH, int OW, int C) 
 extern "C" int cy_maxpool_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int OH, int OW, int ldy,
                               int k, int stride, int pad, uint8_t* argmax, void* scratch, int dtype, cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!x || !y || !scratch || C % ch || ldx % ch || ldy % ch || k < 1 || k > 15 || stride < 1) return CY_ERR_ARG;
     uint8_t* a1 = argmax;
     uint8_t* b1 = argmax ? argmax + (size_t)N * OH * OW * C : nullptr;
@@ -825,7 +844,7 @@ extern "C" int cy_maxpool_fwd(const void* x, int N, int H, int W, int C, int ldx
                        OW, k, stride, pad, b1);                                                                         \
     hipLaunchKernelGGL((maxpool_cols_kernel<T>), dim3(g2), dim3(256), 0, cy_s(s), (const T*)scratch, N, H, C, (T*)y, OH,  \
                        OW, ldy, k, stride, pad, a1);
-    CY_DT_SWITCH(dtype, CY_MP(f16), CY_MP(float))
+    CY_DT_SWITCH(dtype, CY_MP)
 #undef CY_MP
     CY_LAUNCH_CHECK();
     return 0;
@@ -835,7 +854,7 @@ extern "C" int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int 
                               int H, int W, int lddx, int k, int stride, int pad, int accumulate, float* scratch,
                               int dtype, cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!dy || !argmax || !dx || !scratch || C % ch || lddy % ch || lddx % ch || stride < 1) return CY_ERR_ARG;
     const uint8_t* a1 = argmax;
     const uint8_t* b1 = argmax + (size_t)N * OH * OW * C;
@@ -846,7 +865,7 @@ extern "C" int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int 
                        scratch, H, k, stride, pad);                                                                       \
     hipLaunchKernelGGL((maxpool_bwd_rows_kernel<T>), dim3(g2), dim3(256), 0, cy_s(s), (const float*)scratch, b1, N, H, OW, C, \
                        (T*)dx, W, lddx, k, stride, pad, accumulate);
-    CY_DT_SWITCH(dtype, CY_MB(f16), CY_MB(float))
+    CY_DT_SWITCH(dtype, CY_MB)
 #undef CY_MB
     CY_LAUNCH_CHECK();
     return 0;
@@ -855,12 +874,12 @@ extern "C" int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int 
 extern "C" int cy_upsample_fwd(const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, int stride,
                                int dtype, cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!x || !y || C % ch || ldx % ch || ldy % ch || stride < 1) return CY_ERR_ARG;
     const int g = grid_for((long)N * H * W * stride * stride * (C / ch));
 #define CY_UF(T) \
     hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), (const T*)x, N, H, W, C, ldx, (T*)y, ldy, stride);
-    CY_DT_SWITCH(dtype, CY_UF(f16), CY_UF(float))
+    CY_DT_SWITCH(dtype, CY_UF)
 #undef CY_UF
     CY_LAUNCH_CHECK();
     return 0;
@@ -869,12 +888,12 @@ extern "C" int cy_upsample_fwd(const void* x, int N, int H, int W, int C, int ld
 extern "C" int cy_upsample_bwd(const void* dy, int N, int H, int W, int C, int lddy, void* dx, int lddx, int stride,
                                int accumulate, int dtype, cy_stream_t s) {
     CY_ENTER();
-    const int ch = dtype == CY_F16 ? 8 : 4;
+    const int ch = dtype == CY_F32 ? 4 : 8;
     if (!dy || !dx || C % ch || lddy % ch || lddx % ch || stride < 1) return CY_ERR_ARG;
     const int g = grid_for((long)N * H * W * (C / ch));
 #define CY_UB(T) \
     hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), (const T*)dy, N, H, W, C, lddy, (T*)dx, lddx, stride, accumulate);
-    CY_DT_SWITCH(dtype, CY_UB(f16), CY_UB(float))
+    CY_DT_SWITCH(dtype, CY_UB)
 #undef CY_UB
     CY_LAUNCH_CHECK();
     return 0;
@@ -887,7 +906,7 @@ extern "C" int cy_f32_to_view(const float* x, int64_t M, int C, float scale, con
     const int g = grid_for(M * CPad);
 #define CY_FV(T) \
     hipLaunchKernelGGL((f32_to_view_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), x, (long)M, C, scale, scale_dev, (T*)y, ldy, CPad, 0);
-    CY_DT_SWITCH(dtype, CY_FV(f16), CY_FV(float))
+    CY_DT_SWITCH(dtype, CY_FV)
 #undef CY_FV
     CY_LAUNCH_CHECK();
     return 0;
@@ -900,7 +919,7 @@ extern "C" int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int C
     const int g = grid_for((long)N * H * W);
 #define CY_NH(T) \
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), x, N, C, H, W, CPad, (T*)out);
-    CY_DT_SWITCH(dtype, CY_NH(f16), CY_NH(float))
+    CY_DT_SWITCH(dtype, CY_NH)
 #undef CY_NH
     CY_LAUNCH_CHECK();
     return 0;
@@ -913,7 +932,7 @@ extern "C" int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad
     const int g = grid_for((long)CoPad * ks * ks * CiPad);
 #define CY_PW(T) \
     hipLaunchKernelGGL((pack_weights_kernel<T>), dim3(g), dim3(256), 0, cy_s(s), w, Co, Ci, ks, CoPad, CiPad, (T*)wf, (T*)wd);
-    CY_DT_SWITCH(dtype, CY_PW(f16), CY_PW(float))
+    CY_DT_SWITCH(dtype, CY_PW)
 #undef CY_PW
     CY_LAUNCH_CHECK();
     return 0;
@@ -928,12 +947,16 @@ extern "C" int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* bl
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_weights_multi_kernel<f16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (9 * 64 + 8) * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_weights_multi_kernel<bf16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (9 * 64 + 8) * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_weights_multi_kernel<float>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (9 * 64 + 4) * 4);
         attr_done = true;
     }
     if (dtype == CY_F16)
         hipLaunchKernelGGL((pack_weights_multi_kernel<f16>), dim3(nblocks), dim3(256), 64 * (9 * 64 + 8) * 2, cy_s(s), desc, blocks);
+    else if (dtype == CY_BF16)
+        hipLaunchKernelGGL((pack_weights_multi_kernel<bf16>), dim3(nblocks), dim3(256), 64 * (9 * 64 + 8) * 2, cy_s(s), desc, blocks);
     else if (dtype == CY_F32)
         hipLaunchKernelGGL((pack_weights_multi_kernel<float>), dim3(nblocks), dim3(256), 64 * (9 * 64 + 4) * 4, cy_s(s), desc, blocks);
     else

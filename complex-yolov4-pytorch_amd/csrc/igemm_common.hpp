@@ -1,6 +1,7 @@
-// Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip: generic gather kernel; conv_halo.hip:
-// 3x3 stride-1 kernel that keeps an input patch with its halo resident in LDS): launch parameters, the MFMA
-// fragment helpers and the common epilogue (BN batch statistics, eval-mode affine + activation, packed NHWC stores).
+// Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip: 4-wave double-buffered gather kernels, every
+// dtype and shape; conv_pipe.hip: 8-wave 3-stage pipelined kernel for the 16-bit modes): launch parameters, the 16x16
+// MFMA fragment helpers and conv_igemm.hip's epilogue (BN batch statistics, eval-mode affine + activation, packed NHWC
+// stores).
 #pragma once
 #include <type_traits>
 
@@ -31,9 +32,10 @@ struct IgemmParams {
     const float* aff_shift;
     const unsigned char* res;
     int act, ldres;
-    int dbg_nomma;   // CY_IGEMM_NOMMA bit mask: timing experiments (1 no MFMA, 4 no stores, 8 no stats, 16 one K step)
-    unsigned x_bias;              // igemm_fast_kernel: bytes the gather descriptor's base sits below g (>= any negative row offset)
-    int halo_xbuf, halo_pieces;   // conv_halo.hip: bytes / 8-row pieces of one LDS input patch
+    unsigned x_bias;              // fast / pipelined kernels: bytes the gather descriptor's base sits below g (>= any negative row offset)
+    int bm_eff;                   // conv_pipe.hip: pixels per tile actually used (<= the kernel's tile capacity)
+    int stat_rows;                // rows of the stats table: 64 = bins shared by blocks (atomics, bin = tile % 64);
+                                  // otherwise one row per pixel tile (one add per address: run-to-run deterministic)
 };
 
 template <typename T>
@@ -48,6 +50,18 @@ struct Mma<f16> {
     }
     __device__ static __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Mma<bf16> {
+    static constexpr int KSTEPS = 2;
+    typedef bf16x8 frag;
+    __device__ static __forceinline__ frag load(const unsigned char* row_ptr, int kk, int lane) {
+        const int c = (kk * 4 + (lane >> 4)) ^ (lane & 7);
+        return *reinterpret_cast<const frag*>(row_ptr + (c << 4));
+    }
+    __device__ static __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
 };
 template <>
@@ -93,7 +107,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     const bool f32out = (p.flags & CY_CONV_BIAS_F32OUT) != 0;
     const bool accum = (p.flags & CY_CONV_ACCUM) != 0;
 
-    if ((p.flags & CY_CONV_STATS) && !(p.dbg_nomma & 8)) {
+    if (p.flags & CY_CONV_STATS) {
         // per channel (sum, sumsq) of this block's BM pixels: 16-lane DPP row sums -> LDS [wm][2][BN] -> one coalesced
         // fp32 atomic per (channel, moment) into one of 64 bins (at most blocks/64 adds per address, no fold launch)
         if constexpr (SYNC_FIRST) __syncthreads();
@@ -122,7 +136,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             }
         }
         __syncthreads();
-        float* srow = p.stats + (size_t)(lid & 63) * 2 * p.OC;
+        float* srow = p.stats + (size_t)(p.stat_rows == 64 ? (lid & 63) : tm) * 2 * p.OC;
         for (int c = tid; c < 2 * BN; c += NT) {
             const int mom = c / BN, cl = c - mom * BN, co = tn * BN + cl;
             float t = 0.f;
@@ -136,7 +150,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int mj = mbase + j * 16;
-        if (mj >= p.M || (p.dbg_nomma & 4)) continue;
+        if (mj >= p.M) continue;
         int m = mj;
         if (sublattice) {
             const int n = mj / ohw, rem = mj - n * ohw;
@@ -171,22 +185,23 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                         if (accum) t += dst[r];
                         dst[r] = t;
                     }
-            } else if (sizeof(T) == 2) {
-                f16* dst = reinterpret_cast<f16*>(p.o) + (size_t)m * p.ldo + co;
+            } else if constexpr (sizeof(T) == 2) {
+                typedef T tx4 __attribute__((ext_vector_type(4)));
+                T* dst = reinterpret_cast<T*>(p.o) + (size_t)m * p.ldo + co;
                 if (co + 3 < p.OC) {
                     if (accum) {
-                        const f16x4 old = *reinterpret_cast<const f16x4*>(dst);
+                        const tx4 old = *reinterpret_cast<const tx4*>(dst);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
                     }
-                    f16x4 h;
+                    tx4 h;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h[r] = (f16)v[r];
-                    *reinterpret_cast<f16x4*>(dst) = h;
+                    for (int r = 0; r < 4; ++r) h[r] = (T)v[r];
+                    *reinterpret_cast<tx4*>(dst) = h;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (co + r < p.OC) dst[r] = (f16)(v[r] + (accum ? (float)dst[r] : 0.f));
+                        if (co + r < p.OC) dst[r] = (T)(v[r] + (accum ? (float)dst[r] : 0.f));
                 }
             } else {
                 float* dst = reinterpret_cast<float*>(p.o) + (size_t)m * p.ldo + co;
@@ -208,6 +223,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 
 }  // namespace cyk
 
-// conv_halo.hip: launches the LDS-resident-patch 3x3 kernel when the shape qualifies (*used = 1), else leaves the launch
-// to the generic kernel (*used = 0).
-int cy_halo3x3_try(const cyk::IgemmParams& p, int dtype, hipStream_t s, int* used);
+// conv_pipe.hip: launches the pipelined kernel when the shape qualifies (*used = 1), else leaves the launch to
+// conv_igemm.hip (*used = 0).
+int cy_pipe_try(const cyk::IgemmParams& p, int dtype, hipStream_t s, int* used);

@@ -13,7 +13,9 @@ Differences from the reference that a caller can observe (all deliberate, SURVEY
     step and train.py discards it, #15); with ``targets=None`` it is a CPU tensor as in the reference;
   * parameter gradients are accumulated by the backward kernels straight into one flat fp32 buffer whose
     slices are the parameters' ``.grad`` (this is what the data-parallel wrapper all-reduces);
-  * ``dtype='f16'`` (default) computes in fp16 with fp32 accumulation; ``dtype='f32'`` is the parity mode.
+  * ``dtype='f16'`` (default) / ``'bf16'`` store activations and packed weights in 16 bits and accumulate in fp32
+    (bf16 needs no loss scaling); ``dtype='f32'`` is the parity mode;
+  * ``deterministic=True`` replaces the fp32-atomic reductions by fixed-order ones: repeats are bit-identical.
 """
 import math
 
@@ -85,13 +87,14 @@ class _StepFn(torch.autograd.Function):
 
 
 class Darknet(nn.Module):
-    def __init__(self, cfgfile, use_giou_loss, dtype='f16', loss_scale=None):
+    def __init__(self, cfgfile, use_giou_loss, dtype='f16', loss_scale=None, deterministic=False):
         super(Darknet, self).__init__()
         self.use_giou_loss = use_giou_loss
         self.blocks = parse_cfg(cfgfile)
         self.width = int(self.blocks[0]['width'])
         self.height = int(self.blocks[0]['height'])
         self.dtype_code = ops.dtype_code(dtype)
+        self.deterministic = bool(deterministic)     # fixed-order reductions: bit-identical repeats (see Engine)
         # static scale applied to d(logits) before it enters the fp16 backward and removed in the parameter-gradient
         # reductions.  Default 1: at random init the gradients are LARGE (a scale of 1024 overflows fp16 on
         # complex_yolov4.cfg); measured on the mini cfg the gradient error does not depend on it between 1 and 1024.
@@ -216,9 +219,10 @@ class Darknet(nn.Module):
         pk = (H, W)
         if pk not in self._plans:
             self._plans[pk] = Plan(self.blocks, H, W, ops.chunk(self.dtype_code))
-        ek = (N, H, W, self.training, str(x.device))
+        ek = (N, H, W, self.training, str(x.device), self.deterministic)
         if ek not in self._engines:
-            self._engines[ek] = Engine(self._plans[pk], N, self.dtype_code, x.device, self.training)
+            self._engines[ek] = Engine(self._plans[pk], N, self.dtype_code, x.device, self.training,
+                                       deterministic=self.deterministic)
         return self._engines[ek]
 
     def release_engines(self):

@@ -21,9 +21,17 @@ def _pad32(c):
     return (c + 31) // 32 * 32
 
 
+_CONV_TUNE_MEMO = {}      # (kind, shape key) -> best kernel / tile hint, shared by every engine of the process
+
+
 class Engine:
-    def __init__(self, plan, N, dt, device, training):
+    def __init__(self, plan, N, dt, device, training, deterministic=False):
         self.plan, self.N, self.dt, self.device, self.training = plan, N, dt, device, training
+        # deterministic: every reduction that the default mode runs through fp32 atomics into shared bins (BatchNorm batch
+        # statistics in the conv epilogue, BatchNorm backward sums) gets one table row per contributing block and is folded
+        # in a fixed order -- two runs of the same step are bit-identical.  Costs larger tables and slower folds.
+        self.det = bool(deterministic)
+        self._fwd_tile, self._dgrad_tile, self._fwd_tuned, self._dgrad_tuned = {}, {}, False, False
         self.tdt = ops.torch_dtype(dt)
         self.act, self.gact = {}, {}
         f32 = dict(dtype=torch.float32, device=device)
@@ -48,7 +56,6 @@ class Engine:
         max_wpart = 0
         self.wsplit, self.wslab_off, self.wsplit_cap = {}, {}, {}
         self._views, self._view_refs = {}, []
-        self._stat_rows = ops.conv_stats_rows(1, 1)
         self._wgrad_tuned = False
         for rec in plan.convs:
             C, M = rec['cout'], N * rec['H'] * rec['W']
@@ -58,10 +65,10 @@ class Engine:
             self.wd[rec['idx']] = torch.empty(cip, kk * cop, dtype=self.tdt, device=device) if training and not rec['first'] else None
             if rec['bn']:
                 self.bnvec[rec['idx']] = torch.empty(4, C, **f32)
-                max_stats = max(max_stats, (ops.conv_stats_rows(M, C) + ops.bn_scratch_rows()) * 2 * C)
+                max_stats = max(max_stats, ops.conv_stats_rows(M, C, self.det) * 2 * C)
                 max_c = max(max_c, C)
                 if training:
-                    max_bnrows = max(max_bnrows, (ops.bn_bwd_rows(M, C, dt) + ops.bn_scratch_rows()) * 2 * C)
+                    max_bnrows = max(max_bnrows, ops.bn_bwd_rows(M, C, dt, self.det) * 2 * C)
             if training:
                 sp = ops.wgrad_split(M, cop, cip, rec['ks'])
                 # room for the split autotuner (first backward) to move away from the heuristic's choice
@@ -137,6 +144,8 @@ class Engine:
             ops.nchw_to_nhwc(x, plan.input.C, self.dt, out=self.view(plan.input))
             self.params = params
             self._pack_all(weights_epoch)
+            if not self._fwd_tuned:
+                self._autotune_fwd()
             for rec in plan.fwd:
                 getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
         return self.outputs
@@ -194,7 +203,7 @@ class Engine:
         counts, and input + output + weights each touched once in the storage dtype."""
         M = self.N * rec['H'] * rec['W']
         kk = rec['ks'] * rec['ks']
-        es = 2 if self.dt == ops.CY_F16 else 4
+        es = 4 if self.dt == ops.CY_F32 else 2
         flops = 2.0 * M * rec['cout'] * kk * rec['cin']
         nbytes = es * (self.N * rec['xH'] * rec['xW'] * rec['cin'] + M * rec['cout'] + rec['cout'] * kk * rec['cin'])
         return flops, nbytes
@@ -222,9 +231,9 @@ class Engine:
         C, M = rec['cout'], raw.M
         if self.training:
             with ops.prof('igemm', *self._conv_work(rec)):
-                ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=CONV_STATS,
-                               stats=self.stats)
-            ops.bn_finalize(self.stats, self._stat_rows, C, M, P[bname + '.weight'], P[bname + '.bias'],
+                ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=self._stat_flags,
+                               stats=self.stats, tile=self._fwd_tile.get(idx, 0))
+            ops.bn_finalize(self.stats, ops.conv_stats_rows(M, C, self.det), C, M, P[bname + '.weight'], P[bname + '.bias'],
                             P[bname + '.running_mean'], P[bname + '.running_var'],
                             P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, mean, invstd, scale, shift)
         else:
@@ -235,7 +244,7 @@ class Engine:
             res = self.view(rec['res']) if rec['res'] is not None else None
             with ops.prof('igemm', *self._conv_work(rec)):
                 ops.conv_bn_act_eval(xv, self.wf[idx], cop, self.view(rec['out']), rec['ks'], rec['stride'], rec['pad'],
-                                     scale, shift, ops.ACT[rec['act']], res)
+                                     scale, shift, ops.ACT[rec['act']], res, tile=self._fwd_tile.get(idx, 0))
             return
         res = self.view(rec['res']) if rec['res'] is not None else None
         ops.bn_act_fwd(raw, self.view(rec['out']), res, scale, shift, ops.ACT[rec['act']])
@@ -281,6 +290,8 @@ class Engine:
         self.act_scale = float(loss_scale if act_scale is None else act_scale)
         if not self._wgrad_tuned:
             self._autotune_wgrad()
+        if not self._dgrad_tuned:
+            self._autotune_dgrad()
         if self._reduce_groups is None or self._reduce_key != grads[next(iter(grads))].data_ptr():
             self._build_reduce_groups()
         flush_at = {g['last']: g for g in self._reduce_groups}
@@ -351,6 +362,86 @@ class Engine:
             self.wsplit[idx] = memo[key]
         self._reduce_groups = None
 
+    # ---- conv kernel / tile choice ---------------------------------------------------------------------
+    @property
+    def _stat_flags(self):
+        return CONV_STATS | (ops.CONV_STATS_DET if self.det else 0)
+
+    def _tunable(self):
+        return (getattr(self.device, 'type', str(self.device)) == 'cuda' and self.dt != CY_F32 and hasattr(ops, 'CONV_TILE_HINTS')
+                and os.environ.get('CY_CONV_AUTOTUNE', '1') != '0')
+
+    def _time_hints(self, key, launch, cin, cout):
+        """Best kernel / tile hint for one conv launch shape: time every candidate (1 warm-up + 3 launches between HIP
+        events) and keep the fastest.  The 4-wave and the 8-wave kernels are within +-10 % of each other on v4's layers and
+        the winner depends on how tiles quantise over the 256 CUs, so it is measured, once per shape and process."""
+        best = _CONV_TUNE_MEMO.get(key)
+        if best is not None:
+            return best
+        hints = [1]
+        if cin % 64 == 0 and cout % 8 == 0:
+            hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h == 3 and cout <= 64)]
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best, best_t = 1, None
+        for h in hints:
+            launch(h)
+            ev0.record()
+            for _ in range(3):
+                launch(h)
+            ev1.record()
+            ev1.synchronize()
+            t = ev0.elapsed_time(ev1)
+            if best_t is None or t < best_t * 0.98:      # a challenger must win by 2 %: ties keep the earlier candidate
+                best, best_t = h, t
+        _CONV_TUNE_MEMO[key] = best
+        return best
+
+    def _autotune_fwd(self):
+        self._fwd_tuned = True
+        if not self._tunable():
+            return
+        for rec in self.plan.convs:
+            if not rec['bn']:
+                continue
+            idx, cop = rec['idx'], _pad32(rec['cout'])
+            xv = self.view(rec['x'])
+            if self.training:
+                raw = self.view(rec['raw'])
+                key = ('fwd', self.dt, self.det, xv.N, xv.H, xv.W, xv.C, xv.ld, raw.C, raw.ld, rec['ks'], rec['stride'])
+                self._fwd_tile[idx] = self._time_hints(key, lambda h: ops.conv_igemm(
+                    xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=self._stat_flags, stats=self.stats,
+                    tile=h), xv.C, raw.C)
+            else:
+                out = self.view(rec['out'])
+                res = self.view(rec['res']) if rec['res'] is not None else None
+                vec = self.bnvec[idx]
+                key = ('eval', self.dt, xv.N, xv.H, xv.W, xv.C, xv.ld, out.C, out.ld, rec['ks'], rec['stride'], res is not None)
+                self._fwd_tile[idx] = self._time_hints(key, lambda h: ops.conv_bn_act_eval(
+                    xv, self.wf[idx], cop, out, rec['ks'], rec['stride'], rec['pad'], vec[2], vec[3], ops.ACT[rec['act']], res,
+                    tile=h), xv.C, out.C)
+        self.stats.zero_()        # the timed launches added into the statistics table
+
+    def _autotune_dgrad(self):
+        self._dgrad_tuned = True
+        if not self._tunable():
+            return
+        heads = {id(h['conv']): i for i, h in enumerate(self.plan.heads)}
+        for b in self.plan.bwd:
+            if b['op'] not in ('conv_bwd', 'head_conv_bwd'):
+                continue
+            rec = b['fwd']
+            dy = self.head_tmp[heads[id(rec)]] if id(rec) in heads else self.view(rec['out'], grad=True)
+            wd, x = self.wd[rec['idx']], rec['x']
+            for ref, acc in b['dx']:
+                r0 = ref.c0 - x.c0
+                gv = self.view(ref, grad=True)
+                flags = CONV_TRANSPOSED | (CONV_ACCUM if acc else 0)
+                key = ('dgrad', self.dt, dy.N, dy.H, dy.W, dy.C, dy.ld, gv.H, gv.W, gv.C, gv.ld, rec['ks'], rec['stride'], acc)
+                # (timing an accumulating launch adds garbage into a gradient buffer that the real backward has not written
+                # yet at this point: every first writer of the step stores)
+                self._dgrad_tile[(rec['idx'], ref.c0)] = self._time_hints(key, lambda h: ops.conv_igemm(
+                    dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], flags=flags, tile=h), dy.C, ref.C)
+
     def _wgrad(self, rec, dy, xv):
         """Weight gradient of one conv.  It is off the critical path of backward (only the optimizer needs it), so it
         is issued on a side HIP stream: its MFMA blocks fill the tails of, and run beside, the HBM-bound BN passes and
@@ -382,7 +473,8 @@ class Engine:
             fl, by = self._conv_work(rec)
             with ops.prof('igemm', fl * ref.C / x.C, by):
                 ops.conv_igemm(dy, wd[r0:r0 + ref.C], ref.C, self.view(ref, grad=True), rec['ks'], rec['stride'],
-                               rec['pad'], flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0))
+                               rec['pad'], flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0),
+                               tile=self._dgrad_tile.get((rec['idx'], ref.c0), 0))
 
     def _b_conv_bwd(self, b):
         rec = b['fwd']
@@ -393,8 +485,9 @@ class Engine:
         raw, g = self.view(rec['raw']), self.view(rec['out'], grad=True)
         C, M = rec['cout'], raw.M
         act = ops.ACT[rec['act']]
-        ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, self.bnpart)
-        ops.bn_bwd_finalize(self.bnpart, ops.bn_bwd_rows(M, C, self.dt), C, self.dgs, self.dbs,
+        rows = ops.bn_bwd_rows(M, C, self.dt, self.det)
+        ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, self.bnpart, rows)
+        ops.bn_bwd_finalize(self.bnpart, rows, C, self.dgs, self.dbs,
                             self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls)
         res_view, res_acc = None, False
         runs = b['res_runs']

@@ -8,11 +8,12 @@ import torch
 
 from ._lib import CyoloError, lib
 
-CY_F16, CY_F32 = 0, 2
+CY_F16, CY_BF16, CY_F32 = 0, 1, 2
 ACT = {'linear': 0, 'leaky': 1, 'mish': 2}
-CONV_STATS, CONV_BIAS_F32OUT, CONV_ACCUM, CONV_TRANSPOSED = 1, 2, 4, 8
-_TORCH_DT = {CY_F16: torch.float16, CY_F32: torch.float32}
-_ELSIZE = {CY_F16: 2, CY_F32: 4}
+CONV_STATS, CONV_BIAS_F32OUT, CONV_ACCUM, CONV_TRANSPOSED, CONV_STATS_DET = 1, 2, 4, 8, 32
+_TORCH_DT = {CY_F16: torch.float16, CY_BF16: torch.bfloat16, CY_F32: torch.float32}
+_ELSIZE = {CY_F16: 2, CY_BF16: 2, CY_F32: 4}
+DTYPE_NAME = {CY_F16: 'f16', CY_BF16: 'bf16', CY_F32: 'f32'}
 
 
 class LaunchProfiler:
@@ -85,9 +86,11 @@ def prof(kind, flops=0.0, nbytes=0.0):
 
 
 def dtype_code(name):
-    """'f16' / 'f32' (or the codes themselves) -> CY_F16 / CY_F32."""
+    """'f16' / 'bf16' / 'f32' (or the codes themselves) -> CY_F16 / CY_BF16 / CY_F32."""
     if name in (CY_F16, 'f16', 'fp16', 'half', torch.float16):
         return CY_F16
+    if name in (CY_BF16, 'bf16', 'bfloat16', torch.bfloat16):
+        return CY_BF16
     if name in (CY_F32, 'f32', 'fp32', 'float', torch.float32):
         return CY_F32
     raise ValueError('unsupported dtype %r' % (name,))
@@ -98,7 +101,7 @@ def torch_dtype(code):
 
 
 def chunk(code):
-    return 8 if code == CY_F16 else 4
+    return 4 if code == CY_F32 else 8
 
 
 _TLS = threading.local()
@@ -293,13 +296,18 @@ def nchw_to_nhwc(x, cpad, dt, out=None):
     return out
 
 
-def halo_launches():
-    """Conv launches since load that ran on the LDS-resident-patch 3x3 kernel (cy_halo_launches)."""
-    return int(lib().raw('cy_halo_launches')())
+def pipe_launches():
+    """Kernel launches since load that ran on the 8-wave pipelined conv kernel (cy_pipe_launches)."""
+    return int(lib().raw('cy_pipe_launches')())
 
 
-def conv_stats_rows(M, OC):
-    return lib().raw('cy_conv_stats_rows')(M, OC)
+def conv_pipe_config(mode=1, cap=0, bn=0, variant=0, bm_eff=0):
+    """Tuning / A-B switch of the conv dispatch (cy_conv_pipe_config): mode 0 never / 1 policy / 2 whenever possible."""
+    lib().call('cy_conv_pipe_config', int(mode), int(cap), int(bn), int(variant), int(bm_eff))
+
+
+def conv_stats_rows(M, OC, det=False):
+    return lib().raw('cy_conv_stats_rows_det' if det else 'cy_conv_stats_rows')(M, OC)
 
 
 def bn_scratch_rows():
@@ -307,18 +315,23 @@ def bn_scratch_rows():
     return lib().raw('cy_bn_scratch_rows')()
 
 
-def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None):
-    """Forward conv (or dgrad with CONV_TRANSPOSED).  g/out: Views; w: packed weight tensor."""
+CONV_TILE_SHIFT = 8
+CONV_TILE_HINTS = (1, 2, 3, 4, 5, 6)     # 1: 4-wave kernels; 2-5: pipelined kernel, 128/192/256/384-pixel tile; 6: its own policy
+
+
+def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None, tile=0):
+    """Forward conv (or dgrad with CONV_TRANSPOSED).  g/out: Views; w: packed weight tensor; tile: kernel / tile hint."""
     _require_gpu()
     lib().call('cy_conv_igemm', _p(g), g.N, g.H, g.W, g.C, g.ld, _p(w), wrows, _p(out), out.H, out.W, out.C, out.ld, ks,
-               stride, pad, g.dt, flags, _p(bias), _p(stats), None, _stream())
+               stride, pad, g.dt, flags | (tile << CONV_TILE_SHIFT), _p(bias), _p(stats), None, _stream())
 
 
-def conv_bn_act_eval(g, w, wrows, out, ks, stride, pad, scale, shift, act, res=None):
+def conv_bn_act_eval(g, w, wrows, out, ks, stride, pad, scale, shift, act, res=None, tile=0):
     """Eval-mode conv + BN affine + activation (+ shortcut) in one kernel."""
     _require_gpu()
     lib().call('cy_conv_bn_act_eval', _p(g), g.N, g.H, g.W, g.C, g.ld, _p(w), wrows, _p(out), out.H, out.W, out.C, out.ld, ks,
-               stride, pad, g.dt, _p(scale), _p(shift), act, _p(res), res.ld if res is not None else 0, _stream())
+               stride, pad, g.dt, _p(scale), _p(shift), act, _p(res), res.ld if res is not None else 0,
+               tile << CONV_TILE_SHIFT, _stream())
 
 
 def wgrad_split(M, Co, Ci, ks):
@@ -351,13 +364,14 @@ def bn_act_fwd(x, y, res, scale, shift, act):
                _p(shift), act, x.dt, _stream())
 
 
-def bn_bwd_rows(M, C, dt):
-    return lib().raw('cy_bn_bwd_rows')(M, C, dt)
+def bn_bwd_rows(M, C, dt, det=False):
+    return lib().raw('cy_bn_bwd_rows_det' if det else 'cy_bn_bwd_rows')(M, C, dt)
 
 
-def bn_act_bwd_reduce(x, dy, mean, invstd, scale, shift, act, part):
+def bn_act_bwd_reduce(x, dy, mean, invstd, scale, shift, act, part, rows=None):
+    rows = bn_bwd_rows(x.M, x.C, x.dt) if rows is None else rows
     lib().call('cy_bn_act_bwd_reduce', _p(x), x.ld, _p(dy), dy.ld, x.M, x.C, _p(mean), _p(invstd), _p(scale), _p(shift),
-               act, x.dt, _p(part), _stream())
+               act, x.dt, _p(part), rows, _stream())
 
 
 def bn_bwd_finalize(part, rows, C, dgs, dbs, ggamma, gbeta, gscale):

@@ -24,11 +24,15 @@ extern "C" {
 
 typedef void* cy_stream_t; /* a hipStream_t */
 
-enum { CY_F16 = 0, CY_F32 = 2 };
+enum { CY_F16 = 0, CY_BF16 = 1, CY_F32 = 2 };
 enum { CY_ACT_LINEAR = 0, CY_ACT_LEAKY = 1, CY_ACT_MISH = 2 };
 enum { CY_ERR_ARG = -1 };
 /* cy_conv_igemm flags */
-enum { CY_CONV_STATS = 1, CY_CONV_BIAS_F32OUT = 2, CY_CONV_ACCUM = 4, CY_CONV_TRANSPOSED = 8, CY_CONV_AFFINE_ACT = 16 };
+enum { CY_CONV_STATS = 1, CY_CONV_BIAS_F32OUT = 2, CY_CONV_ACCUM = 4, CY_CONV_TRANSPOSED = 8, CY_CONV_AFFINE_ACT = 16,
+       CY_CONV_STATS_DET = 32 };
+/* bits 8-11 of `flags`: kernel / tile hint of the call (0 = library default), see cy_conv_igemm */
+enum { CY_CONV_TILE_SHIFT = 8 };
+#define CY_CONV_TILE(h) ((h) << CY_CONV_TILE_SHIFT)
 
 int cy_version(void);
 /* Number of compute units / wavefront size of the current device (sanity for the loader). */
@@ -101,24 +105,38 @@ int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dt
  *                               be zero on entry; cy_bn_finalize folds it and leaves it zeroed.
  *        CY_CONV_BIAS_F32OUT -> out is float regardless of dtype and bias[OC] is added (the YOLO head convs)
  *        CY_CONV_ACCUM       -> out += result (gradient fan-in of routes / shortcuts)
+ *        CY_CONV_TILE(h)     -> which kernel runs the call (results are the same; a caller that launches the same shape
+ *                               every step times the candidates once): 0 library default, 1 the 4-wave kernels, 2-5 the
+ *                               8-wave pipelined kernel with a 128 / 192 / 256 / 384-pixel tile, 6 with its own tile policy
+ *                               (the hint is ignored where that kernel does not apply: f32, first layers, fp32 output)
  * Returns the number of stats rows written through *stats_rows when non-NULL. */
 int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out, int OH,
                   int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags, const float* bias,
                   float* stats_part, int* stats_rows_host, cy_stream_t s);
 /* Eval-mode conv block in ONE kernel: out = act(conv(g, w) * scale[co] + shift[co]) (+ res), scale/shift being the
  * BatchNorm affine of the running statistics (cy_bn_eval_affine).  The pre-BN tensor is never written
- * (reference: the same nn.Sequential under model.eval(), evaluate.py:32-44). */
+ * (reference: the same nn.Sequential under model.eval(), evaluate.py:32-44).  flags: 0 or CY_CONV_TILE(h). */
 int cy_conv_bn_act_eval(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out,
                         int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, const float* scale,
-                        const float* shift, int act, const void* res, int ldres, cy_stream_t s);
+                        const float* shift, int act, const void* res, int ldres, int flags, cy_stream_t s);
 
-/* Number of cy_conv_igemm / cy_conv_bn_act_eval calls since load that ran on the LDS-resident-patch kernel
- * (opt-in with CY_HALO=1: 3x3, stride 1, pad 1, Cin a multiple of 64 f16 / 32 f32 channels, Cout > 32;
- * csrc/conv_halo.hip); every other call runs on the generic gather kernel.  Diagnostics for tests and profiles. */
-int64_t cy_halo_launches(void);
+/* Number of kernel launches since load that ran on the 8-wave pipelined kernel (csrc/conv_pipe.hip: CY_F16 / CY_BF16,
+ * Cin a multiple of 64, 16-bit output with OC and ldo multiples of 8, enough pixel tiles to fill the chip); every
+ * other launch runs on conv_igemm.hip's 4-wave kernels.  Diagnostics for tests and profiles. */
+int64_t cy_pipe_launches(void);
+/* Test / tool switch, not used on the step path.  mode 0: never use the pipelined kernel, 1: default (hints and the
+ * eval-mode epilogue select it), 2: every launch that qualifies; cap x bn (0 x 0 = policy) forces a tile capacity out of
+ * {384,256,192,128} x 128 / {384,256,128} x 64 with bm_eff (0 = cap) pixels of it used; variant 0: shipped (3-stage ring,
+ * LDS-transposed stores), 1: direct stores from the MFMA layout (what CY_CONV_ACCUM launches use), 2: 2-stage ring.
+ * CY_CONV_PIPE=0 in the environment = mode 0. */
+int cy_conv_pipe_config(int mode, int cap, int bn, int variant, int bm_eff);
 
 /* Number of rows (bins) of the stats table cy_conv_igemm adds into (64). */
 int cy_conv_stats_rows(int M, int OC);
+/* With CY_CONV_STATS | CY_CONV_STATS_DET every pixel tile adds into its OWN row (one add per address onto zero: the
+ * table, and everything computed from it, is bit-identical from run to run -- fp32 atomics into shared bins are not).
+ * Upper bound of the rows the table needs; cy_bn_finalize takes the same number and folds them in a fixed order. */
+int cy_conv_stats_rows_det(int M, int OC);
 /* Extra rows a partial table needs behind it (0 since the binned-atomics version; kept for ABI stability). */
 int cy_bn_scratch_rows(void);
 
@@ -148,11 +166,13 @@ int cy_bn_eval_affine(const float* gamma, const float* beta, const float* runnin
 int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
                   const float* scale, const float* shift, int act, int dtype, cy_stream_t s);
 /* Backward pass 1: per-channel partial sums of dz and dz*xhat, dz = dy*act'(x*scale+shift), ADDED (fp32 atomics) into
- * part[bin][2][C], cy_bn_bwd_rows() bins; zero on entry, cy_bn_bwd_finalize folds it and leaves it zeroed. */
+ * part[row][2][C]; zero on entry, cy_bn_bwd_finalize(rows) folds it and leaves it zeroed.  rows = cy_bn_bwd_rows()
+ * (64 bins shared by the blocks) or cy_bn_bwd_rows_det() (one row per block: run-to-run deterministic). */
 int cy_bn_act_bwd_reduce(const void* x, int ldx, const void* dy, int lddy, int64_t M, int C, const float* mean,
                          const float* invstd, const float* scale, const float* shift, int act, int dtype,
-                         float* part, cy_stream_t s);
+                         float* part, int rows, cy_stream_t s);
 int cy_bn_bwd_rows(int64_t M, int C, int dtype);
+int cy_bn_bwd_rows_det(int64_t M, int C, int dtype);
 /* Fold the partials: dgamma_sum[C], dbeta_sum[C] (raw sums, used by the apply pass) and accumulate
  * gscale*sums into the parameter gradients ggamma/gbeta (+=). */
 int cy_bn_bwd_finalize(const float* part, int rows, int C, float* dgamma_sum, float* dbeta_sum, float* ggamma,

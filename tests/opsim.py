@@ -77,7 +77,7 @@ def wgrad_reduce_multi(desc, blocks, scale, accumulate):
         wgrad_reduce(part, split, corows, cip, ks, Co, Ci, scale, accumulate, grad)
 
 
-def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None):
+def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None, tile=0):
     x = _nchw(g)
     kk = ks * ks
     if flags & CONV_TRANSPOSED:
@@ -98,7 +98,7 @@ def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None
     _store(out, y, accumulate=bool(flags & CONV_ACCUM))
 
 
-def conv_bn_act_eval(g, w, wrows, out, ks, stride, pad, scale, shift, act, res=None):
+def conv_bn_act_eval(g, w, wrows, out, ks, stride, pad, scale, shift, act, res=None, tile=0):
     x = _nchw(g)
     wt = w.float().reshape(w.shape[0], ks * ks, g.C)[:out.C].permute(0, 2, 1).reshape(out.C, g.C, ks, ks)
     y = F.conv2d(x, wt, None, stride, pad)
@@ -162,9 +162,9 @@ def _dz(x, dy, scale, shift, act):
     return g
 
 
-def bn_act_bwd_reduce(x, dy, mean, invstd, scale, shift, act, part):
+def bn_act_bwd_reduce(x, dy, mean, invstd, scale, shift, act, part, rows=None):
     C = x.C
-    rows = real.bn_bwd_rows(x.M, C, x.dt)
+    rows = real.bn_bwd_rows(x.M, C, x.dt) if rows is None else rows
     dz = _dz(x, dy, scale, shift, act)
     xh = (_nchw(x) - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
     p = part.view(-1)[:rows * 2 * C].view(rows, 2, C)

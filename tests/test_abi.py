@@ -52,7 +52,7 @@ def test_argument_validation_without_launch(built):
     assert lib.raw('cy_sgd_multi')(None, None, 0, 0.9, 1, 1, 0, None, None, 0, None, None) == -1
     assert lib.raw('cy_adam_multi')(None, None, 0, 0.9, 0.999, 1e-8, 0.1, 0.001, 0, None, None, 0, None, None) == -1
     assert lib.raw('cy_bev_workspace')(608, 608) == 608 * 608 * 12
-    assert lib.raw('cy_halo_launches')() >= 0
+    assert lib.raw('cy_pipe_launches')() >= 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-device behaviour')

@@ -13,16 +13,20 @@ pytestmark = pytest.mark.gpu
 
 import complex_yolov4_pytorch_amd.ops as ops  # noqa: E402
 import complex_yolov4_pytorch_amd.synthetic as syn  # noqa: E402
-from complex_yolov4_pytorch_amd.ops import CY_F16, CY_F32, View  # noqa: E402
+from complex_yolov4_pytorch_amd.ops import CY_BF16, CY_F16, CY_F32, View  # noqa: E402
 
 DEV = 'cuda'
 
 
 def _tol(dt):
+    if dt == CY_BF16:       # bf16 rounding of the stored result: 2^-8 relative
+        return dict(rtol=1.6e-2, atol=1.6e-2)
     return dict(rtol=2e-3, atol=2e-3) if dt == CY_F16 else dict(rtol=1e-4, atol=1e-5)
 
 
 def _round(x, dt):
+    if dt == CY_BF16:
+        return x.bfloat16().float()
     return x.half().float() if dt == CY_F16 else x
 
 
@@ -54,7 +58,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dt', [CY_F16, CY_F32])
+@pytest.mark.parametrize('dt', [CY_F16, CY_BF16, CY_F32])
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_forward_and_stats(dt, case):
     N, Ci, H, W, Co, ks, st = case
@@ -76,62 +80,92 @@ def test_conv_forward_and_stats(dt, case):
     torch.testing.assert_close(s[1], (ref.double() ** 2).sum((0, 2, 3)).float(), rtol=1e-3, atol=1e-2)
 
 
-HALO_CASES = [
-    # N, Cin, H, W, Cout, forced tile (None = the library's own choice)
-    (2, 64, 19, 19, 128, '256x128'),
-    (3, 64, 21, 17, 64, '256x64'),      # tiles straddle image boundaries, Cout = 64
-    (2, 128, 13, 29, 160, '128x128'),   # two channel slices (f16), ragged channel tile
-    (1, 192, 38, 38, 64, '128x64'),
-    (5, 64, 76, 76, 128, None),         # 113 blocks of 256 pixels: v4's stride-8 shape
-    (2, 64, 7, 5, 64, '256x64'),        # one partial tile, patch wider than the image
+PIPE_CASES = [
+    # N, Cin, H, W, Cout, ks, stride, (capacity, bn, pixels of the tile used) -- None = the library's own policy
+    (2, 64, 19, 19, 128, 3, 1, (256, 128, 256)),
+    (3, 64, 21, 17, 64, 3, 1, (256, 64, 200)),      # tiles straddle image boundaries, partly used capacity, Cout = 64
+    (2, 128, 13, 29, 160, 3, 1, (128, 128, 128)),   # two channel tiles, the second one ragged
+    (1, 192, 38, 38, 64, 3, 1, (128, 64, 97)),
+    (2, 64, 38, 38, 128, 3, 1, (192, 128, 181)),    # 2 x 4 wave layout
+    (2, 128, 38, 38, 256, 3, 1, (384, 128, 361)),   # 2-stage ring
+    (1, 64, 40, 24, 64, 3, 1, (384, 64, 384)),
+    (5, 64, 76, 76, 128, 3, 1, None),               # v4's stride-8 shape
+    (2, 64, 7, 5, 64, 3, 1, (256, 64, 256)),        # one partial tile
+    (2, 256, 19, 19, 512, 1, 1, (128, 128, 128)),   # 1 x 1
+    (2, 128, 38, 38, 64, 1, 1, (256, 64, 256)),
+    (1, 64, 64, 64, 128, 3, 2, (256, 128, 256)),    # stride 2: forward and the four dgrad parity classes
+    (2, 64, 21, 17, 64, 3, 2, (128, 64, 128)),
 ]
 
 
-@pytest.mark.parametrize('dt', [CY_F16, CY_F32])
-@pytest.mark.parametrize('case', HALO_CASES)
-def test_conv_halo3x3_forward_dgrad(dt, case, monkeypatch):
-    """conv_halo.hip (LDS-resident patch, 3x3 / stride 1) against torch conv2d in float64, forward + BN statistics and
-    dgrad; the generic gather kernel is run on the same call to show the two paths agree."""
-    N, Ci, H, W, Co, tile = case
-    monkeypatch.setenv('CY_HALO', '1')
-    monkeypatch.setenv('CY_HALO_MINBLOCKS', '1')
+@pytest.fixture
+def pipe_policy():
+    yield
+    ops.conv_pipe_config(mode=1)
+
+
+@pytest.mark.parametrize('dt', [CY_F16, CY_BF16])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 5, 6])
+@pytest.mark.parametrize('case', PIPE_CASES)
+def test_conv_pipe_forward_dgrad(dt, variant, case, pipe_policy):
+    """conv_pipe.hip (8 waves, 3-stage counted-vmcnt ring, 32x32x16 MFMA, LDS-transposed stores) against torch conv2d in
+    float64: forward + BN statistics, the eval-mode epilogue with shortcut, dgrad and dgrad-accumulate, for every tile
+    capacity / wave layout / ring depth; the 4-wave kernels run the same call to show the two paths agree."""
+    N, Ci, H, W, Co, ks, st, tile = case
+    if variant and tile is None:
+        pytest.skip('variants are swept on forced tiles')
+    pad = (ks - 1) // 2
+    cfg = dict(mode=2, variant=variant)
     if tile:
-        monkeypatch.setenv('CY_HALO_TILE', tile)
+        cfg.update(cap=tile[0], bn=tile[1], bm_eff=tile[2])
+    ops.conv_pipe_config(**cfg)
     x = _round(_rand(N, Ci, H, W, seed=11), dt)
-    w = _round(_rand(Co, Ci, 3, 3, seed=12, scale=1 / math.sqrt(Ci * 9)), dt)
-    ref = F.conv2d(x.double(), w.double(), None, 1, 1).float()
+    w = _round(_rand(Co, Ci, ks, ks, seed=12, scale=1 / math.sqrt(Ci * ks * ks)), dt)
+    ref = F.conv2d(x.double(), w.double(), None, st, pad).float()
+    OH, OW = ref.shape[2], ref.shape[3]
     xv = View.from_nchw(x.to(DEV), dt, ld=Ci + 2 * ops.chunk(dt)).channels(0, Ci)
     wf, wd = ops.pack_weights(w.to(DEV), Co, Ci, dt)
-    out = View.alloc(N, H, W, Co, dt, ld=Co + 32, zero=True)
-    rows = ops.conv_stats_rows(N * H * W, Co)
+    out = View.alloc(N, OH, OW, Co, dt, ld=Co + 32, zero=True)
+    rows = ops.conv_stats_rows(N * OH * OW, Co)
     stats = torch.zeros(rows, 2, Co, device=DEV)
-    n0 = ops.halo_launches()
-    ops.conv_igemm(xv, wf, Co, out, 3, 1, 1, flags=ops.CONV_STATS, stats=stats)
-    assert ops.halo_launches() == n0 + 1
+    n0 = ops.pipe_launches()
+    ops.conv_igemm(xv, wf, Co, out, ks, st, pad, flags=ops.CONV_STATS, stats=stats)
+    assert ops.pipe_launches() == n0 + 1
     torch.testing.assert_close(out.to_nchw().cpu(), ref, **_tol(dt))
+    assert float(out.buf.view(-1, Co + 32)[:, Co:].abs().max()) == 0.0          # nothing written beside the view
     s = stats.sum(0).cpu()
     torch.testing.assert_close(s[0], ref.double().sum((0, 2, 3)).float(), rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(s[1], (ref.double() ** 2).sum((0, 2, 3)).float(), rtol=1e-3, atol=1e-2)
-    # the generic gather kernel on the same call
-    monkeypatch.setenv('CY_HALO', '0')
-    out2 = View.alloc(N, H, W, Co, dt, zero=True)
-    ops.conv_igemm(xv, wf, Co, out2, 3, 1, 1)
-    assert ops.halo_launches() == n0 + 1
+    # the 4-wave kernels on the same call
+    ops.conv_pipe_config(mode=0)
+    out2 = View.alloc(N, OH, OW, Co, dt, zero=True)
+    ops.conv_igemm(xv, wf, Co, out2, ks, st, pad)
+    assert ops.pipe_launches() == n0 + 1
     torch.testing.assert_close(out2.to_nchw().cpu(), out.to_nchw().cpu(), **_tol(dt))
-    monkeypatch.setenv('CY_HALO', '1')
-    # dgrad (mirrored taps over the [Cin][tap, Cout] pack) + accumulate
-    if Co % (64 if dt == CY_F16 else 32) == 0:
-        dy = _round(_rand(N, Co, H, W, seed=13), dt)
-        wq = _round(_rand(Co, Ci, 3, 3, seed=12, scale=1 / math.sqrt(Co * 9)), dt)
+    ops.conv_pipe_config(**cfg)
+    # eval-mode epilogue: BN affine + Mish + shortcut
+    sc, sh = (_rand(Co, seed=14).abs() + 0.5).to(DEV), _rand(Co, seed=15).to(DEV)
+    res = _round(_rand(N, Co, OH, OW, seed=16), dt)
+    resv = View.from_nchw(res.to(DEV), dt, ld=Co + 8).channels(0, Co)
+    out3 = View.alloc(N, OH, OW, Co, dt, zero=True)
+    ops.conv_bn_act_eval(xv, wf, Co, out3, ks, st, pad, sc, sh, ops.ACT['mish'], resv)
+    assert ops.pipe_launches() == n0 + 2
+    z = ref.double() * sc.cpu().double().view(1, -1, 1, 1) + sh.cpu().double().view(1, -1, 1, 1)
+    want = (z * torch.tanh(F.softplus(z)) + res.double()).float()
+    tol = _tol(dt)
+    torch.testing.assert_close(out3.to_nchw().cpu(), want, rtol=2 * tol['rtol'], atol=2 * tol['atol'])
+    # dgrad (mirrored taps over the [Cin][tap, Cout] pack; stride 2 = four parity-class launches) + accumulate
+    if Co % 64 == 0:
+        dy = _round(_rand(N, Co, OH, OW, seed=13), dt)
+        wq = _round(_rand(Co, Ci, ks, ks, seed=12, scale=1 / math.sqrt(Co * ks * ks)), dt)
         _, wd = ops.pack_weights(wq.to(DEV), Co, Ci, dt)
-        gref = torch.nn.grad.conv2d_input((N, Ci, H, W), wq.double(), dy.double(), 1, 1).float()
+        gref = torch.nn.grad.conv2d_input((N, Ci, H, W), wq.double(), dy.double(), st, pad).float()
         dx = View.alloc(N, H, W, Ci, dt, ld=Ci + 16, zero=True)
-        n1 = ops.halo_launches()
-        ops.conv_igemm(View.from_nchw(dy.to(DEV), dt), wd, Ci, dx, 3, 1, 1, flags=ops.CONV_TRANSPOSED)
-        assert ops.halo_launches() == n1 + 1
-        torch.testing.assert_close(dx.to_nchw().cpu(), gref, **_tol(dt))
-        ops.conv_igemm(View.from_nchw(dy.to(DEV), dt), wd, Ci, dx, 3, 1, 1, flags=ops.CONV_TRANSPOSED | ops.CONV_ACCUM)
-        tol = _tol(dt)
+        n1 = ops.pipe_launches()
+        ops.conv_igemm(View.from_nchw(dy.to(DEV), dt), wd, Ci, dx, ks, st, pad, flags=ops.CONV_TRANSPOSED)
+        assert ops.pipe_launches() == n1 + (4 if st == 2 else 1)
+        torch.testing.assert_close(dx.to_nchw().cpu(), gref, **tol)
+        ops.conv_igemm(View.from_nchw(dy.to(DEV), dt), wd, Ci, dx, ks, st, pad, flags=ops.CONV_TRANSPOSED | ops.CONV_ACCUM)
         torch.testing.assert_close(dx.to_nchw().cpu(), 2 * gref, rtol=2 * tol['rtol'], atol=2 * tol['atol'])
 
 

@@ -9,6 +9,8 @@ import complex_yolov4_pytorch_amd.ops as ops
 from complex_yolov4_pytorch_amd.ops import CY_F16, View
 
 N, Ci, Co, ks, st, H = [int(v) for v in sys.argv[1:7]]
+if os.environ.get('PIPE_CFG'):      # "mode,cap,bn,variant,bm_eff" -> cy_conv_pipe_config (A/B of the two conv kernels)
+    ops.conv_pipe_config(*[int(v) for v in os.environ['PIPE_CFG'].split(',')])
 iters = int(sys.argv[7]) if len(sys.argv) > 7 else 20
 kinds = (sys.argv[8] if len(sys.argv) > 8 else 'fwd,dgrad,wgrad').split(',')
 pad = (ks - 1) // 2

@@ -25,7 +25,7 @@ cnt = collections.defaultdict(int)
 for f in glob.glob('%s/pmc_%s_*/**/*counter_collection.csv' % (root, tag), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'igemm' not in k and 'halo' not in k and 'wgrad' not in k:
+        if 'igemm' not in k and 'wgrad' not in k:
             continue
         k = k.split('(')[0][-60:]
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
