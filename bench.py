@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): BEV images/s of a 608x608 Complex-YOLOv4 TRAIN step.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config train608|infer32|train1024] [--dtype f16|bf16|f32]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-One step = forward + GIoU loss + backward + Adam update of complex_yolov4.cfg on a fixed synthetic batch of 16 BEV
-images per GPU (BASELINE configs[1]); inputs are resident in HBM before the timed region.  Weak scaling: every rank
-runs its own 16 images, gradients are averaged over RCCL (parallel.RcclDataParallel).  Rank 0 prints ONE JSON line with
-`roofline` (the implicit-GEMM conv kernel, timed with HIP events on its launch stream) and `cpu_baseline` (the oracle --
-a CPU restatement of the reference -- timed on this host's cores on a bounded sample).
+train608 (default, BASELINE configs[1]): one step = forward + GIoU loss + backward + Adam update of complex_yolov4.cfg on a
+fixed synthetic batch of 16 BEV images per GPU; inputs are resident in HBM before the timed region.  Weak scaling: every
+rank runs its own 16 images, gradients are averaged over RCCL (parallel.RcclDataParallel).  Rank 0 prints ONE JSON line
+with `roofline` (the implicit-GEMM conv kernel family, timed with HIP events on its launch stream) and `cpu_baseline`
+(the oracle -- a CPU restatement of the reference -- timed on this host's cores on a bounded sample).
+infer32 (configs[3]): model.eval()(imgs) + post_processing_v2 (rotated merge-NMS on the device), batch 32.
+train1024 (configs[4]): the train step at 1024x1024, batch 8.
+The default single-GPU run also measures the other two configurations briefly and reports them under `other_configs`,
+so the one driver line carries configs[1], [3] and [4].
 """
 import argparse
 import json
@@ -29,7 +33,9 @@ from complex_yolov4_pytorch_amd.parallel import RcclDataParallel  # noqa: E402
 from complex_yolov4_pytorch_amd.utils.train_utils import create_optimizer  # noqa: E402
 
 CFG = os.path.join(ROOT, 'complex-yolov4-pytorch_amd', 'config', 'cfg', 'complex_yolov4.cfg')
-MFMA_PEAK_TFLOPS = {'f16': 2500.0, 'f32': 157.3}     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {'f16': 2500.0, 'bf16': 2500.0, 'f32': 157.3}     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+CONFIGS = {'train608': dict(kind='train', batch=16, size=608), 'infer32': dict(kind='infer', batch=32, size=608),
+           'train1024': dict(kind='train', batch=8, size=1024)}
 HBM_PEAK_GBS = 8000.0
 HBM_PEAK_BPS = HBM_PEAK_GBS * 1e9
 
@@ -52,19 +58,38 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
+def kernel_sources_sha():
+    """sha256 over the HIP sources the measured kernels are built from (what a committed PMC figure is valid for)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'complex-yolov4-pytorch_amd', 'csrc', '*.h*'))):
+        with open(f, 'rb') as fh:
+            h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel, a):
     """HBM bytes per launch of the kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate runs of this same command; FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
-    cannot be read from inside the process, so this is the recorded figure for the default workload, or None."""
-    if (a.batch, a.size, a.dtype) != (16, 608, 'f16'):
+    cannot be read from inside the process, so this is the recorded figure for the default workload -- and only while the
+    kernel sources are the ones it was measured on (tools/pmc_traffic.sh stamps their hash and the git head): a stale
+    file yields null, never an old number."""
+    if (a.batch, a.size, a.dtype, a.config) != (16, 608, 'f16', 'train608'):
         return None
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
     try:
         with open(path) as f:
-            d = json.load(f)[kernel]
+            doc = json.load(f)
+        if doc.get('kernel_sources_sha') != kernel_sources_sha():
+            return dict(bytes_per_launch=None, stale=True, measured_on=doc.get('kernel_sources_sha'), now=kernel_sources_sha(),
+                        source='profiles/r02_pmc_hbm_traffic.json')
+        d = doc[kernel]
         return dict(bytes_per_launch=round(d['fetch_bytes_per_launch_corrected'] + d['write_bytes_per_launch']),
                     fetch=round(d['fetch_bytes_per_launch_corrected']), write=round(d['write_bytes_per_launch']),
-                    unit='bytes', source='profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)')
+                    launches_counted=d.get('launches'), unit='bytes', git_head=doc.get('git_head'),
+                    kernel_sources_sha=doc.get('kernel_sources_sha'),
+                    source='profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.sh)')
     except (OSError, KeyError, ValueError):
         return None
 
@@ -100,17 +125,87 @@ def cpu_baseline(batch, size, seconds_budget=20.0):
                        % (n, batch, size, size))
 
 
+def measure_inference(dev, batch, size, dtype, steps, warmup):
+    """BASELINE configs[3]: eval forward of complex_yolov4.cfg + post_processing_v2 (rotated merge-NMS on the device) per
+    batch.  Random-init weights give no confident boxes, so the NMS leg runs on synthetic predictions with 256 candidates
+    per image in the SAME timed step: both stages are paid for every batch."""
+    from complex_yolov4_pytorch_amd.utils.evaluation_utils import post_processing_v2_device
+    torch.manual_seed(0)
+    model = Darknet(CFG, use_giou_loss=True, dtype=dtype).to(dev).eval()
+    model.cpu_outputs = False
+    model.static_eval_weights = True           # serving: parameters do not change between batches
+    x = syn.bev_images(batch, size, seed=0).to(dev)
+    pred = syn.nms_predictions(batch, 3 * ((size // 8) ** 2 + (size // 16) ** 2 + (size // 32) ** 2), 256, seed=4).to(dev)
+
+    def step():
+        with torch.no_grad():
+            out = model(x)
+            post_processing_v2_device(pred, 0.5, 0.5)
+        return out
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    model.release_engines()
+    return dict(metric='BEV images/s (%dx%d) inference + rotated NMS' % (size, size), value=round(batch / dt, 2), unit='images/s',
+                ms_per_step=round(1e3 * dt, 3), steps=steps, dtype=dtype,
+                workload='complex_yolov4.cfg model.eval() forward, batch %d, %dx%d + post_processing_v2 on the device '
+                         '(256 candidates/image)' % (batch, size, size))
+
+
+def measure_train(dev, batch, size, dtype, steps, warmup):
+    """A train step configuration measured briefly on one GPU (the `other_configs` entries of the default run)."""
+    torch.manual_seed(0)
+    model = Darknet(CFG, use_giou_loss=True, dtype=dtype).to(dev)
+    model.train()
+    opt = create_optimizer(_OptCfg, model)
+    x, tg = syn.bev_images(batch, size, seed=0).to(dev), syn.targets(batch, 6, size, seed=0).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = model(x, tg)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    final = float(loss.detach().reshape(-1)[0])
+    model.release_engines()
+    del opt, model
+    torch.cuda.empty_cache()
+    return dict(metric='BEV images/s (%dx%d) train step' % (size, size), value=round(batch / dt, 2), unit='images/s',
+                ms_per_step=round(1e3 * dt, 3), steps=steps, dtype=dtype, loss_final=round(final, 4),
+                workload='complex_yolov4.cfg train step (fwd + rotated-GIoU loss + bwd + Adam), batch %d, %dx%d' % (batch, size, size))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='images per GPU')
-    ap.add_argument('--size', type=int, default=608)
-    ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
+    ap.add_argument('--config', default='train608', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the configuration\'s)')
+    ap.add_argument('--size', type=int, default=None)
+    ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the brief measurement of the other configurations')
     a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    a.batch = a.batch or cfg['batch']
+    a.size = a.size or cfg['size']
 
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -126,6 +221,24 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
+
+    if cfg['kind'] == 'infer':
+        # replicas: every rank serves its own batches, no exchange
+        r = measure_inference(dev, a.batch, a.size, a.dtype, a.steps, a.warmup)
+        t = torch.tensor([r['ms_per_step']], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            ms = float(t)
+            print(json.dumps({'metric': r['metric'], 'value': round(world * a.batch / (ms * 1e-3), 3), 'unit': 'images/s',
+                              'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
+                              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
+                              'data': 'synthetic', 'config': {'workload': r['workload'], 'global_batch': world * a.batch,
+                                                              'parallelism': 'replicas%d' % world},
+                              'roofline': None, 'cpu_baseline': None}))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     torch.manual_seed(0)
     model = Darknet(CFG, use_giou_loss=True, dtype=a.dtype).to(dev)
@@ -161,6 +274,7 @@ def main():
     final_loss = float(loss.detach().reshape(-1)[0])
 
     roofline = None
+    summ, by_bound = {}, None
     if not a.no_roofline:
         # exclusive kernel durations: the probe steps issue the weight-gradient kernels on the main stream (in the timed
         # region they overlap the dgrad/BN kernels from a side stream, which stretches every kernel's own duration).
@@ -173,17 +287,18 @@ def main():
         for _ in range(2):
             step()
         summ = ops.PROFILER.summary() if rank == 0 else {}
-        by_bound = None
         if rank == 0:
-            # the same launches split by which roof bounds them: arithmetic intensity above / below the ridge point
-            over = ops.PROFILER.bracket_overhead_ms()
+            # the same launches split by which roof bounds them: arithmetic intensity above / below the ridge point.
+            # Durations are the RAW event brackets (two event records included, ~5 us): a conservative rate; the figure
+            # with the empty-bracket duration taken out is reported beside it (rocprofv3's exclusive durations of the
+            # same run, profiles/r02_*, sit between the two).
             ridge = MFMA_PEAK_TFLOPS[a.dtype] * 1e12 / HBM_PEAK_BPS
             acc = {'mfma': [0.0, 0.0, 0.0, 0], 'hbm': [0.0, 0.0, 0.0, 0]}
             for kind, fl, nb, ev0, ev1 in ops.PROFILER.records:
                 if kind != 'igemm' or nb <= 0:
                     continue
                 k = 'mfma' if fl / nb >= ridge else 'hbm'
-                t = max(ev0.elapsed_time(ev1) - over, 1e-6)
+                t = max(ev0.elapsed_time(ev1), 1e-6)
                 acc[k][0] += fl; acc[k][1] += nb; acc[k][2] += t; acc[k][3] += 1
             by_bound = {}
             for k, (fl, nb, ms, n) in acc.items():
@@ -196,45 +311,60 @@ def main():
         for e, sd in sides:
             e.side = sd
         sync()
-    if roofline is None and rank == 0 and not a.no_roofline:
+    if rank == 0 and not a.no_roofline:
         ig = summ.get('igemm')
         if ig:
-            ach = ig['flops'] / (ig['ms'] * 1e-3) / 1e12
+            ach = ig['flops'] / (ig['ms_raw'] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[a.dtype]
-            roofline = dict(bound='mfma', kernel='igemm_kernel (implicit-GEMM conv: forward + dgrad launches, all tile variants)',
+            tr = pmc_traffic('igemm', a)
+            roofline = dict(bound='mfma', kernel='implicit-GEMM conv kernels (forward + dgrad launches: igemm_fast_kernel / igemm_kernel '
+                                                 '4-wave tiles and igemm_pipe_kernel 8-wave tiles, chosen per layer)',
                             achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                            traffic=(pmc_traffic('igemm', a) or {}).get('bytes_per_launch'),
-                            traffic_detail=pmc_traffic('igemm', a),
-                            launches_per_step=ig['launches'] // 2, avg_launch_us=round(1e3 * ig['ms'] / ig['launches'], 2),
-                            hbm_gbs_algorithmic=round(ig['bytes'] / (ig['ms'] * 1e-3) / 1e9, 1),
+                            traffic=(tr or {}).get('bytes_per_launch'), traffic_detail=tr,
+                            launches_per_step=ig['launches'] // 2, avg_launch_us=round(1e3 * ig['ms_raw'] / ig['launches'], 2),
+                            hbm_gbs_algorithmic=round(ig['bytes'] / (ig['ms_raw'] * 1e-3) / 1e9, 1),
                             algorithmic_bytes_per_launch=round(ig['bytes'] / ig['launches']),
-                            measured='HIP events around every launch of the kernel on its launch stream, minus the duration of an empty event bracket; 2 extra single-stream steps after the timed region',
-                            avg_launch_us_with_event_overhead=round(1e3 * ig['ms_raw'] / ig['launches'], 2))
+                            measured='HIP events around every launch of the family on its launch stream (raw brackets, event records '
+                                     'included); 2 extra single-stream steps after the timed region',
+                            achieved_minus_event_overhead=round(ig['flops'] / (ig['ms'] * 1e-3) / 1e12, 2),
+                            avg_launch_us_minus_event_overhead=round(1e3 * ig['ms'] / ig['launches'], 2))
             wg = summ.get('wgrad')
             if wg:
-                roofline['wgrad_kernel'] = dict(achieved=round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12, 2), unit='TFLOP/s',
+                roofline['wgrad_kernel'] = dict(achieved=round(wg['flops'] / (wg['ms_raw'] * 1e-3) / 1e12, 2), unit='TFLOP/s',
                                                 launches_per_step=wg['launches'] // 2,
-                                                avg_launch_us=round(1e3 * wg['ms'] / wg['launches'], 2))
-            roofline['conv_ms_per_step'] = round((ig['ms'] + (wg['ms'] if wg else 0)) / 2, 3)
+                                                avg_launch_us=round(1e3 * wg['ms_raw'] / wg['launches'], 2))
+            roofline['conv_ms_per_step'] = round((ig['ms_raw'] + (wg['ms_raw'] if wg else 0)) / 2, 3)
             roofline['by_bound'] = by_bound   # launches above the ridge point against the MFMA peak, the rest against HBM
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         cpu = None
+        others = None
+        if world == 1 and a.config == 'train608' and not a.no_extra:
+            # free this configuration's 17 GB of storages, then measure configs[3] and configs[4] briefly
+            model.release_engines()
+            del opt
+            torch.cuda.empty_cache()
+            others = {'infer32': measure_inference(dev, 32, 608, a.dtype, 8, 3),
+                      'train1024': measure_train(dev, 8, 1024, a.dtype, 5, 2)}
+            if a.dtype == 'f16':
+                others['train608_bf16'] = measure_train(dev, 16, 608, 'bf16', 6, 3)
         if not a.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(2, a.size)
         imgs = world * a.batch * a.steps
         line = {
-            'metric': 'BEV images/s (608x608) train step', 'value': round(imgs / elapsed, 3), 'unit': 'images/s',
+            'metric': 'BEV images/s (%dx%d) train step' % (a.size, a.size), 'value': round(imgs / elapsed, 3), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * elapsed / a.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f16' if a.dtype == 'f16' else 'f32', 'data': 'synthetic',
+            'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': 'complex_yolov4.cfg train step (fwd + rotated-GIoU loss + bwd + Adam), batch %d per GPU, %dx%dx3 synthetic BEV, 6 targets/image'
                                    % (a.batch, a.size, a.size),
                        'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4)},
             'roofline': roofline, 'cpu_baseline': cpu,
         }
+        if others:
+            line['other_configs'] = others
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -347,7 +347,6 @@ int launch_general(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.OC + BN - 1) / BN;
-    if (p.stat_rows != 64) p.stat_rows = p.mtiles;
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
@@ -365,7 +364,6 @@ int launch_fast(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = (p.OC + BN - 1) / BN;
-    if (p.stat_rows != 64) p.stat_rows = p.mtiles;
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
@@ -467,7 +465,7 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
     p.ks = ks; p.stride = stride; p.pad = pad; p.transposed = (flags & CY_CONV_TRANSPOSED) ? 1 : 0;
     p.K = ks * ks * GC; p.M = N * OH * OW; p.wrows = wrows; p.flags = flags;
     p.mtiles = p.ntiles = 0; p.bm_eff = 0;
-    p.stat_rows = (flags & CY_CONV_STATS_DET) ? 0 : 64;
+    p.stat_det = (flags & CY_CONV_STATS_DET) ? 1 : 0;
     if (p.M <= 0 || OC <= 0) return CY_ERR_ARG;
     if (stats_rows_host) *stats_rows_host = (flags & CY_CONV_STATS_DET) ? cy_conv_stats_rows_det(p.M, OC) : cy_conv_stats_rows(p.M, OC);
     const size_t esz = dtype == CY_F32 ? 4 : 2;

@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pipe_kernel(const IgemmParams p)
             }
         }
         __syncthreads();
-        float* srow = p.stats + (size_t)(p.stat_rows == 64 ? (lid & 63) : tm) * 2 * p.OC;
+        float* srow = p.stats + (size_t)(p.stat_det ? tm : (lid & 63)) * 2 * p.OC;
         for (int c = tid; c < 2 * BN; c += 512) {
             const int mom = c / BN, cl = c - mom * BN, co = tn * BN + cl;
             float t = 0.f;
@@ -519,7 +519,6 @@ int cy_pipe_try(const cyk::IgemmParams& p0, int dtype, hipStream_t s, int* used)
     if (g_pipe_cap) { cap = g_pipe_cap; bn = g_pipe_bn; eff = g_pipe_bm_eff ? g_pipe_bm_eff : cap; }
     if (eff > cap) return CY_ERR_ARG;
     p.bm_eff = eff;
-    if (p.stat_rows != 64) p.stat_rows = (p.M + eff - 1) / eff;    // deterministic statistics: one table row per pixel tile
     const int rc = dtype == CY_F16 ? pipe_dispatch<f16>(p, cap, bn, g_pipe_variant, s) : pipe_dispatch<bf16>(p, cap, bn, g_pipe_variant, s);
     if (rc == 0) { *used = 1; ++g_pipe_launches; }
     return rc;

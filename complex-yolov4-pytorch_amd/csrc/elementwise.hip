@@ -1012,12 +1012,12 @@ extern "C" int cy_grad_nonfinite(const float* g, int64_t n, int32_t* flag, cy_st
 }
 
 extern "C" int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, const float* scale_dev,
-                            float* gbias, cy_stream_t s) {
+                            float* gbias, int deterministic, cy_stream_t s) {
     CY_ENTER();
     if (!dlogits || !gbias || C < 1 || C > 32) return CY_ERR_ARG;
     long blocks = (M + 8 * 32 - 1) / (8 * 32);   // >= 32 rows per row lane
     if (blocks > 512) blocks = 512;
-    if (blocks < 1) blocks = 1;
+    if (blocks < 1 || deterministic) blocks = 1;  // one block = one add per channel: the sum does not depend on block order
     hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, cy_s(s), dlogits, (long)M, C, scale, scale_dev, gbias);
     CY_LAUNCH_CHECK();
     return 0;

@@ -509,7 +509,8 @@ class Engine:
         M, nch = self.N * hd['G'] * hd['G'], hd['A'] * (7 + hd['C'])
         tmp = self.head_tmp[h]
         ops.f32_to_view(self.dlogits[h], M, nch, self.act_scale, tmp, 32, scale_dev=self.gout)
-        ops.bias_grad(self.dlogits[h], M, nch, self.act_scale / self.ls, self.grads[cname + '.bias'], scale_dev=self.gout)
+        ops.bias_grad(self.dlogits[h], M, nch, self.act_scale / self.ls, self.grads[cname + '.bias'], scale_dev=self.gout,
+                      deterministic=self.det)
         self._wgrad(rec, tmp, self.view(rec['x']))
         self._dgrad(rec, tmp, b['dx'])
 

@@ -425,8 +425,8 @@ def zero_view(y, dummy):
     lib().call('cy_f32_to_view', _p(dummy), y.M, 0, 0.0, None, _p(y), y.ld, y.C, y.dt, _stream())
 
 
-def bias_grad(dlogits, M, C, scale, gbias, scale_dev=None):
-    lib().call('cy_bias_grad', _p(dlogits), M, C, float(scale), _p(scale_dev), _p(gbias), _stream())
+def bias_grad(dlogits, M, C, scale, gbias, scale_dev=None, deterministic=False):
+    lib().call('cy_bias_grad', _p(dlogits), M, C, float(scale), _p(scale_dev), _p(gbias), int(deterministic), _stream())
 
 
 # ---- YOLO head ------------------------------------------------------------------------------------

@@ -33,6 +33,34 @@ def post_processing_v2_device(prediction, conf_thresh=0.95, nms_thresh=0.4):
     return ops.pp2(_dev(prediction).float(), conf_thresh, nms_thresh)
 
 
+def load_classes(path):
+    """Class names, one per line (reference evaluation_utils.py:43-49; host-only helper kept for import compatibility)."""
+    with open(path, 'r') as fp:
+        return fp.read().split('\n')[:-1]
+
+
+def post_processing(outputs, conf_thresh=0.95, nms_thresh=0.4):
+    """The reference's first post-processing variant (evaluation_utils.py:279-318): per image keep the rows whose
+    objectness x best class score exceeds ``conf_thresh``, greedy rotated NMS on that score (``nms_cpu`` = cy_rnms_greedy),
+    rows (x, y, w, l, im, re, object_conf, score, class).  The reference indexes its 2-D objectness array with three
+    subscripts (:305) and raises IndexError on every call; this is the function it evidently meant, kept so that
+    ``from utils.evaluation_utils import post_processing`` (evaluate.py:20) resolves.  -> list of np.ndarray [K, 9] / None."""
+    out = outputs.detach().cpu().numpy() if torch.is_tensor(outputs) else np.asarray(outputs)
+    confs = out[:, :, 6:7] * out[:, :, 7:]
+    max_conf, max_id = confs.max(axis=2), confs.argmax(axis=2)
+    result = [None] * out.shape[0]
+    for i in range(out.shape[0]):
+        sel = max_conf[i] > conf_thresh
+        if not sel.any():
+            continue
+        boxes, obj, score, cls = out[i, sel, :6], out[i, sel, 6], max_conf[i, sel], max_id[i, sel]
+        keep = nms_cpu(boxes, score, nms_thresh=nms_thresh)
+        if keep.size > 0:
+            result[i] = np.concatenate((boxes[keep], obj[keep].reshape(-1, 1), score[keep].reshape(-1, 1),
+                                        cls[keep].reshape(-1, 1).astype(out.dtype)), axis=-1)
+    return result
+
+
 def nms_cpu(boxes, confs, nms_thresh=0.5):
     """boxes [K,6] (x,y,w,l,im,re), confs [K] -> np.ndarray of kept indices (highest confidence first)."""
     b = _dev(np.ascontiguousarray(boxes, dtype=np.float32) if not torch.is_tensor(boxes) else boxes)

@@ -209,9 +209,10 @@ int cy_f32_to_view(const float* x, int64_t M, int C, float scale, const float* s
                    int dtype, cy_stream_t s);
 /* bias gradient of a head conv (C <= 32): gbias[c] += scale * sum_p dlogits[p][c].
  * In both calls the effective factor is scale * (*scale_dev) when scale_dev is non-NULL (the upstream
- * d(loss) scalar stays on the device: no host synchronisation in backward). */
+ * d(loss) scalar stays on the device: no host synchronisation in backward).  deterministic != 0: one block does the
+ * whole sum (no cross-block float atomics; slower). */
 int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, const float* scale_dev, float* gbias,
-                 cy_stream_t s);
+                 int deterministic, cy_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * YOLO head  (reference models/yolo_layer.py)

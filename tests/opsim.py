@@ -255,7 +255,7 @@ def zero_view(y, dummy):
     _t(y).zero_()
 
 
-def bias_grad(dlogits, M, C, scale, gbias, scale_dev=None):
+def bias_grad(dlogits, M, C, scale, gbias, scale_dev=None, deterministic=False):
     sc = scale * (float(scale_dev.reshape(-1)[0]) if scale_dev is not None else 1.0)
     gbias += sc * dlogits.view(-1)[:M * C].view(M, C).sum(0)
 

@@ -8,12 +8,14 @@ root=$(pwd)
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$root/gpurun_out/pmc_$c
   rm -rf $out
-  (cd /tmp && CY_WGRAD_AUTOTUNE=0 rocprofv3 --pmc $c --output-format csv -d $out -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $root/gpurun_out/pmc_$c.log 2>&1)
+  (cd /tmp && CY_WGRAD_AUTOTUNE=0 rocprofv3 --pmc $c --output-format csv -d $out -- python $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra > $root/gpurun_out/pmc_$c.log 2>&1)
 done
-python - "$root/gpurun_out" <<'PY'
-import csv, glob, json, sys, collections
+python - "$root/gpurun_out" "$root" <<'PY'
+import csv, glob, json, os, sys, collections
 root = sys.argv[1]
-FAM = [('igemm', ('igemm_fast_kernel', 'igemm_kernel', 'halo3x3_kernel')), ('wgrad', ('wgrad_dma_kernel', 'wgrad_kernel')),
+sys.path.insert(0, sys.argv[2])
+import bench
+FAM = [('igemm', ('igemm_fast_kernel', 'igemm_kernel', 'igemm_pipe_kernel')), ('wgrad', ('wgrad_dma_kernel', 'wgrad_kernel')),
        ('wgrad_reduce', ('wgrad_reduce',)), ('bn_act_fwd', ('bn_act_fwd',)), ('bn_bwd_reduce', ('bn_bwd_reduce',)),
        ('bn_bwd_apply', ('bn_bwd_apply',)), ('bn_bwd_finalize', ('bn_bwd_finalize',)), ('bn_finalize', ('bn_finalize',)),
        ('pack_weights', ('pack_weights',)), ('adam', ('adam_multi',))]
@@ -35,13 +37,15 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     for k, v in n.items():
         agg[k]['launches'] = max(agg[k]['launches'], v)
 # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-units of 1024? -> the counters are in KB (1 KB = 1024 B) per the tool's derived metric
-out = {}
+out = {'kernel_sources_sha': bench.kernel_sources_sha(), 'git_head': os.environ.get('GIT_HEAD', 'unknown'),
+       'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra (CY_WGRAD_AUTOTUNE=0)'}
 for k, v in sorted(agg.items()):
     L = max(1, v['launches'])
     out[k] = dict(launches=v['launches'], fetch_bytes_per_launch_corrected=2.0 * 1024.0 * v['FETCH_SIZE'] / L,
                   write_bytes_per_launch=1024.0 * v['WRITE_SIZE'] / L)
 json.dump(out, open(root + '/pmc_hbm_traffic.json', 'w'), indent=1)
 for k, v in out.items():
-    print('%-16s launches %5d  fetch %8.2f MB  write %8.2f MB per launch' % (k, v['launches'], v['fetch_bytes_per_launch_corrected'] / 1e6, v['write_bytes_per_launch'] / 1e6))
+    if isinstance(v, dict):
+        print('%-16s launches %5d  fetch %8.2f MB  write %8.2f MB per launch' % (k, v['launches'], v['fetch_bytes_per_launch_corrected'] / 1e6, v['write_bytes_per_launch'] / 1e6))
 PY
 find $root/gpurun_out/pmc_FETCH_SIZE $root/gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +1M -delete
