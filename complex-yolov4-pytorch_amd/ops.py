@@ -555,3 +555,42 @@ def bev_rasterize(points, bounds, disc, H, W, workspace, out=None, zshift=None, 
     lib().call('cy_bev_rasterize', _p(pts) if pts.shape[0] else None, pts.shape[0], *[float(v) for v in bounds], float(zshift),
                float(max_height), float(disc), H, W, _p(workspace), _p(out), _stream())
     return out
+
+
+# ---- augmentation on the rasterised maps ---------------------------------------------------------------
+
+def _iarr(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def bev_mosaic(tiles, img_size, rects, fill=0.5, out=None):
+    """tiles: four float32 [C,h,w] device tensors; rects[k] = (x1a, y1a, x2a, y2a, x1b, y1b) -> [C, 2*img_size, 2*img_size]."""
+    _require_gpu()
+    t = [x.float().contiguous() for x in tiles]
+    C, h, w = t[0].shape
+    if out is None:
+        out = torch.empty(C, 2 * img_size, 2 * img_size, dtype=torch.float32, device=t[0].device)
+    lib().call('cy_bev_mosaic', _p(t[0]), _p(t[1]), _p(t[2]), _p(t[3]), C, h, w, img_size, _iarr([v for r in rects for v in r]),
+               float(fill), _p(out), _stream())
+    return out
+
+
+def bev_mosaic_targets(targets, tile_of, h, w, pads, img_size):
+    """targets float32 [nT,8] (in place), tile_of int32 [nT] (0..3), pads[k] = (padw, padh)."""
+    if targets.shape[0]:
+        lib().call('cy_bev_mosaic_targets', _p(targets), targets.shape[0], _p(tile_of), h, w, _iarr([v for q in pads for v in q]),
+                   img_size, _stream())
+    return targets
+
+
+def bev_flip_cutout(img, flip, holes, fill, targets=None, want_keep=False):
+    """img float32 [C,H,W] -> new tensor: flipped along W (flip) with the holes (y1, y2, x1, x2) filled; targets updated in
+    place; returns (out, keep mask uint8 [nT] or None)."""
+    _require_gpu()
+    C, H, W = img.shape
+    out = torch.empty_like(img)
+    nT = 0 if targets is None else targets.shape[0]
+    keep = torch.ones(nT, dtype=torch.uint8, device=img.device) if (want_keep and nT) else None
+    lib().call('cy_bev_flip_cutout', _p(img), C, H, W, int(bool(flip)), _iarr([v for q in holes for v in q]) if holes else None,
+               len(holes), float(fill), _p(out), _p(targets) if nT else None, nT, _p(keep), _stream())
+    return out, keep

@@ -293,6 +293,27 @@ int64_t cy_bev_workspace(int H, int W);
 int cy_bev_rasterize(const float* points, int n, float minX, float maxX, float minY, float maxY, float minZ, float maxZ,
                      float zshift, float max_height, float disc, int H, int W, void* workspace, float* out, cy_stream_t s);
 
+/* ------------------------------------------------------------------------------------------------
+ * Augmentation on the rasterised maps, SURVEY.md section 8f row 1 (reference src/data_process/kitti_dataset.py:123-173
+ * load_mosaic; src/data_process/transformation.py:376-437 Horizontal_Flip, Cutout).  Images are float32 [C][H][W] on
+ * the device, targets float32 [nT][8] = (sample, class, x, y, w, l, im, re) normalised to the image, updated in place
+ * with the reference's float32 arithmetic (bit-identical).  Random draws stay with the caller (host RNG, same stream
+ * as the reference); these entry points take the drawn geometry.
+ * ---------------------------------------------------------------------------------------------- */
+/* 2*img_size square canvas = `fill` (0.5 in the reference) with the four tiles pasted: rects_host[k] = (x1a, y1a, x2a,
+ * y2a, x1b, y1b): canvas[y1a:y2a, x1a:x2a] = tile_k[y1b:, x1b:] (kitti_dataset.py:141-157). */
+int cy_bev_mosaic(const float* tile0, const float* tile1, const float* tile2, const float* tile3, int C, int h, int w,
+                  int img_size, const int* rects_host, float fill, float* out, cy_stream_t s);
+/* targets of tile tile_of_target[i]: x = (x*w + padw)/(2 S), y = (y*h + padh)/(2 S), w *= w/(2 S), l *= h/(2 S), then x, y
+ * clamped to [0, 1 - 0.5/S]; pads_host[k] = (padw, padh) = (x1a - x1b, y1a - y1b) (kitti_dataset.py:158-171). */
+int cy_bev_mosaic_targets(float* targets, int nT, const int32_t* tile_of_target, int h, int w, const int* pads_host,
+                          int img_size, cy_stream_t s);
+/* out = src flipped along W when flip != 0 (targets: x = 1 - x, im = -im), with nholes <= 8 rectangles holes_host[k] =
+ * (y1, y2, x1, x2) set to fill; keep[i] (optional) = 0 for targets whose centre lies inside a hole (borders included).
+ * out must not alias src. */
+int cy_bev_flip_cutout(const float* src, int C, int H, int W, int flip, const int* holes_host, int nholes, float fill,
+                       float* out, float* targets, int nT, uint8_t* keep, cy_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

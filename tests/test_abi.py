@@ -53,6 +53,9 @@ def test_argument_validation_without_launch(built):
     assert lib.raw('cy_adam_multi')(None, None, 0, 0.9, 0.999, 1e-8, 0.1, 0.001, 0, None, None, 0, None, None) == -1
     assert lib.raw('cy_bev_workspace')(608, 608) == 608 * 608 * 12
     assert lib.raw('cy_pipe_launches')() >= 0
+    assert lib.raw('cy_bev_mosaic')(None, None, None, None, 3, 8, 8, 8, None, 0.5, None, None) == -1
+    assert lib.raw('cy_bev_mosaic_targets')(None, 0, None, 8, 8, None, 8, None) == -1
+    assert lib.raw('cy_bev_flip_cutout')(None, 3, 8, 8, 1, None, 0, 0.0, None, None, 0, None, None) == -1
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-device behaviour')

@@ -196,3 +196,51 @@ def test_conv_large_grids(dt, case):
     # sums of ~M products of unit-variance numbers: compare relative to the tensor's scale
     scale = float(wref.abs().max())
     assert float((gw.cpu() - wref).abs().max()) <= (3e-2 if dt == CY_BF16 else 4e-3 if dt == CY_F16 else 2e-4) * scale
+
+
+def _sha(t):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32).tobytes()).hexdigest()
+
+
+def test_device_augmentation_matches_reference(golden):
+    """SURVEY section 8f row 1, VERDICT r1 missing #2: Horizontal_Flip / Cutout / Compose and the mosaic of
+    KittiDataset.load_mosaic on the device against the reference's own outputs (tests/golden/aug.npz, produced by
+    make_golden_aug.py from the unmodified reference with the same host RNG seeds): pixels and target rows bit-identical."""
+    import random
+    from complex_yolov4_pytorch_amd.data_process import transformation as T
+    g = golden('aug')
+    img = syn.bev_images(1, 608, seed=51)[0].to(DEV)
+    tg = syn.targets(1, 6, 608, seed=51)
+    np.random.seed(1)
+    fi, ft = T.Horizontal_Flip(p=1.0)(img.clone(), tg.clone())
+    assert fi.is_cuda and _sha(fi) == str(g['flip_sha'])
+    np.testing.assert_array_equal(ft.cpu().numpy(), g['flip_targets'])
+    np.random.seed(int(g['cut_seed'][0]))
+    ci, ct = T.Cutout(n_holes=3, ratio=0.25, fill_value=0.5, p=1.0)(img.clone(), tg.clone())
+    assert _sha(ci) == str(g['cut_sha'])
+    np.testing.assert_array_equal(ct.cpu().numpy(), g['cut_targets'])
+    assert 0 < ct.shape[0] < tg.shape[0]                          # the case drops a target
+    comp = T.Compose([T.Horizontal_Flip(p=1.0), T.Cutout(n_holes=12, ratio=0.1, fill_value=0.0, p=1.0)], p=1.0)
+    np.random.seed(77)
+    pi, pt = comp(img.clone(), tg.clone())
+    assert _sha(pi) == str(g['comp_sha'])
+    np.testing.assert_array_equal(pt.cpu().numpy(), g['comp_targets'])
+    np.random.seed(5)                                              # p gates: nothing happens, inputs returned untouched
+    ni, nt = T.Horizontal_Flip(p=0.0)(img, tg)
+    assert ni is img and nt is tg
+    tiles = [syn.bev_images(1, 608, seed=60 + k)[0].to(DEV) for k in range(4)]
+    tts = [syn.targets(1, 6, 608, seed=60 + k) for k in range(4)]
+    for tag, rp in (('mosaic_fixed', False), ('mosaic_rand_a', True), ('mosaic_rand_b', True)):
+        random.seed(int(g[tag + '_seed'][0]))
+        canvas, targets = T.make_mosaic(tiles, [t.clone() for t in tts], 608, random_padding=rp)
+        assert tuple(canvas.shape) == (3, 1216, 1216) and _sha(canvas) == str(g[tag + '_sha']), tag
+        np.testing.assert_array_equal(canvas[:, ::97, ::89].cpu().numpy(), g[tag + '_rows'])
+        np.testing.assert_array_equal(targets.cpu().numpy(), g[tag + '_targets'])
+    # the mosaic canvas feeds the train step (BASELINE configs[2]: "mosaic aug on" = a 1216 x 1216 input)
+    model = _model('complex_yolov4_tiny.cfg', 'f16')
+    model.train()
+    t = targets.clone(); t[:, 0] = 0
+    loss, out = model(canvas[None], t.to(DEV))
+    loss.backward()
+    assert np.isfinite(float(loss.detach())) and out.shape[1] == 3 * (76 * 76 + 38 * 38)
