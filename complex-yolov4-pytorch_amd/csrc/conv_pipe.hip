@@ -48,22 +48,32 @@ __device__ __forceinline__ float half32_sum(float v) {
     return v + __shfl_xor(v, 16, 64);
 }
 
-template <typename T, int BM, int BN, int WN, int NST, bool EPI_LDS>
-__global__ void __launch_bounds__(512, 2) igemm_pipe_kernel(const IgemmParams p) {
+// LOADERS = 0: the eight waves stage their own share of every tile.  LOADERS = 4: four extra waves (one per SIMD) do
+// nothing but issue the DMA pieces and their scalar / vector address arithmetic, the eight compute waves nothing but
+// fragment reads and MFMAs: with two waves per SIMD the ~100 cycles a wave spends issuing each buffer_load ... lds
+// (48-64 per K step and CU) are cycles its MFMAs do not issue -- measured, the bare MFMA loop of a 72-step tile takes
+// 32 us, 43 us with the DMA issue in the same waves, 51 us with the fragment reads too.
+template <typename T, int BM, int BN, int WN, int NST, bool EPI_LDS, int LOADERS>
+__global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pipe_kernel(const IgemmParams p) {
     constexpr int WM = 8 / WN;                                // waves over channels x waves over pixels
     constexpr int TI = BN / (32 * WN), TJ = BM / (32 * WM);   // 32 x 32 fragments per wave: channels, pixels
-    constexpr int XP = BM / 64, WP = BN / 64, NP = XP + WP;   // 1 KB DMA pieces per wave per K tile
+    constexpr int NLD = LOADERS ? LOADERS : 8;                // waves that stage tiles
+    constexpr int XP = BM / (8 * NLD), WP = BN / (8 * NLD), NP = XP + WP;   // 1 KB DMA pieces per staging wave per K tile
+    static_assert(BM % (8 * NLD) == 0 && BN % (8 * NLD) == 0, "pieces per staging wave");
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int BK = 64;
     static_assert(BM % (32 * WM) == 0 && BM % 64 == 0 && BN % (32 * WN) == 0 && BN % 64 == 0 && NST >= 2 && NST <= 3, "tile / wave layout");
-    static_assert(NP <= 12, "vmcnt budget");
+    static_assert(2 * NP <= 48, "vmcnt budget");
     typedef typename Mma32<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* orow = reinterpret_cast<unsigned*>(smem + NST * STAGE);   // byte offset of every tile row's output pixel
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave % WN, wm = wave / WN;
+    const bool is_loader = LOADERS && wave >= 8;              // wave-uniform role
+    const bool stages = !LOADERS || is_loader;
+    const int lw = LOADERS ? (wave - 8) & (NLD - 1) : wave;   // index among the staging waves
+    const int wn = (wave & 7) % WN, wm = (wave & 7) / WN;
     int lid;
     {
         const int nblk = gridDim.x, bid = blockIdx.x;
@@ -107,13 +117,13 @@ __global__ void __launch_bounds__(512, 2) igemm_pipe_kernel(const IgemmParams p)
             orow[tid] = obyte;
         }
         __syncthreads();
-        // DMA lane l of a piece fills physical chunk l & 7 of row (l >> 3): it fetches logical chunk (l & 7) ^ f(row),
-        // f(row) = (row >> 1) & 7 = ((wave & 1) << 2) | (l >> 4) for the rows wave * 8 + 64 * i + (l >> 3) of this wave
-        const int chunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+        // staging wave lw owns the pieces lw + NLD * i (8 rows each).  DMA lane l of a piece fills physical chunk l & 7 of
+        // row (l >> 3): it fetches logical chunk (l & 7) ^ f(row), f(row) = (row >> 1) & 7 = ((lw & 1) << 2) | (l >> 4)
+        const int chunk = (lane & 7) ^ (((lw & 1) << 2) | (lane >> 4));
         const unsigned lane_const = (unsigned)p.x_bias + (unsigned)dmin + (unsigned)(chunk * 16);
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const uint2 ri = rowinfo[wave * 8 + (lane >> 3) + 64 * i];
+            const uint2 ri = rowinfo[(lw + NLD * i) * 8 + (lane >> 3)];
             xoff[i] = ri.x + lane_const;
             ximask[i] = (int)~ri.y;
         }
@@ -121,10 +131,10 @@ __global__ void __launch_bounds__(512, 2) igemm_pipe_kernel(const IgemmParams p)
     }
     unsigned woff[WP];
     {
-        const int chunk = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+        const int chunk = (lane & 7) ^ (((lw & 1) << 2) | (lane >> 4));
 #pragma unroll
         for (int i = 0; i < WP; ++i) {
-            const int row = tn * BN + wave * 8 + (lane >> 3) + 64 * i;
+            const int row = tn * BN + (lw + NLD * i) * 8 + (lane >> 3);
             woff[i] = row < p.wrows ? ((unsigned)row * (unsigned)p.K * (unsigned)sizeof(T) + (unsigned)(chunk * 16)) : 0xFFFFFFFFu;
         }
     }
@@ -146,19 +156,19 @@ __global__ void __launch_bounds__(512, 2) igemm_pipe_kernel(const IgemmParams p)
         w_soff = (unsigned)(((kh * p.ks + kw) * p.GC + l_c) * (int)sizeof(T));
         ld_tap = real ? l_tap : 31;         // bit 31 of the inverted tap mask is always set -> every row out of range
         ld_oob = real ? 0u : 0xFFFFFFFFu;
-        ld_dst = smem + stage * STAGE + wave * (8 * 128);
+        ld_dst = smem + stage * STAGE + lw * (8 * 128);
         l_c += BK;
         if (l_c >= p.GC) { l_c = 0; ++l_tap; }
     };
     auto issue_piece = [&](int pc) {        // pc: compile-time after unrolling
         if (pc < XP) {
             const unsigned v = xoff[pc] | (unsigned)(-((ximask[pc] >> ld_tap) & 1));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(ld_dst + pc * (64 * 128)), 16, v,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(ld_dst + pc * (NLD * 8 * 128)), 16, v,
                                                      x_soff, 0, 0);
         } else {
             const unsigned v = woff[pc - XP] | ld_oob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rs_w, (__attribute__((address_space(3))) void*)(ld_dst + BM * 128 + (pc - XP) * (64 * 128)), 16, v, w_soff, 0, 0);
+                rs_w, (__attribute__((address_space(3))) void*)(ld_dst + BM * 128 + (pc - XP) * (NLD * 8 * 128)), 16, v, w_soff, 0, 0);
         }
     };
     auto issue_all = [&]() {
@@ -207,7 +217,42 @@ __global__ void __launch_bounds__(512, 2) igemm_pipe_kernel(const IgemmParams p)
     // pieces of a tile spread over the 4 sub-steps of a K step: sub-step s issues [s * NP / 4, (s + 1) * NP / 4)
     const int nkt = p.ntaps * (p.GC / BK);
 
-    if constexpr (NST == 3) {
+    if constexpr (LOADERS > 0) {
+        // Loader / compute split over the same 3-stage ring and the same barrier protocol: at the barrier that opens step kt
+        // the loaders have retired their pieces of tile kt (counted vmcnt: tile kt + 1 may still fly) and the compute
+        // waves are done with tile kt - 1, whose stage the loaders refill with tile kt + 2 while the compute waves read and
+        // multiply tile kt.  Both roles execute exactly one barrier per step.
+        static_assert(NST == 3, "the specialised variant runs on the 3-stage ring");
+        if (is_loader) {
+            begin_tile(0); issue_all();
+            begin_tile(1); issue_all();
+            begin_tile(2);
+            int cs = 0;
+            for (int kt = 0; kt < nkt; ++kt) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_all();
+                begin_tile(cs);
+                cs = cs == 2 ? 0 : cs + 1;
+            }
+        } else {
+            int cs = 0;
+            for (int kt = 0; kt < nkt; ++kt) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                load(0, cs, 0);
+                load(1, cs, 1);
+                mma_sub(0, -1, 0);
+                load(0, cs, 2);
+                mma_sub(1, -1, 0);
+                load(1, cs, 3);
+                mma_sub(0, -1, 0);
+                mma_sub(1, -1, 0);
+                cs = cs == 2 ? 0 : cs + 1;
+            }
+        }
+    } else if constexpr (NST == 3) {
         // Top barrier.  Tile kt lives in stage kt % 3.  At the top of step kt this wave has tiles kt and kt + 1 in flight:
         // waiting for vmcnt <= NP retires tile kt (in-order return); the barrier then (a) makes every wave's pieces of
         // tile kt visible and (b) says every wave is done reading stage (kt + 2) % 3, which is refilled during this step.
@@ -253,6 +298,10 @@ __global__ void __launch_bounds__(512, 2) igemm_pipe_kernel(const IgemmParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy tiles' zero fills must not land on the epilogue's LDS use
     __syncthreads();   // every wave is done with the ring: the epilogue reuses it
+    if (is_loader) {   // the loaders hold no results; they only keep the block's barrier count whole
+        if (p.flags & CY_CONV_STATS) { __syncthreads(); __syncthreads(); }
+        return;
+    }
 
     // ---- epilogue -----------------------------------------------------------------------------------------------------
     // lane holds D[co = cw + i*32 + 8*g + 4*(lane>>5) + r][pixel row = pw + j*32 + (lane&31)], acc register 4*g + r
@@ -417,7 +466,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pipe_kernel(const IgemmParams p)
     }
 }
 
-template <typename T, int BM, int BN, int WN, int NST, bool EPI_LDS>
+template <typename T, int BM, int BN, int WN, int NST, bool EPI_LDS, int LOADERS = 0>
 int pipe_launch(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
     p.mtiles = (p.M + p.bm_eff - 1) / p.bm_eff;
@@ -426,25 +475,25 @@ int pipe_launch(const IgemmParams& p0, hipStream_t s) {
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<T, BM, BN, WN, NST, EPI_LDS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<T, BM, BN, WN, NST, EPI_LDS, LOADERS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_pipe_kernel<T, BM, BN, WN, NST, EPI_LDS>), dim3(p.mtiles * p.ntiles), dim3(512), smem, s, p);
+    hipLaunchKernelGGL((igemm_pipe_kernel<T, BM, BN, WN, NST, EPI_LDS, LOADERS>), dim3(p.mtiles * p.ntiles), dim3(512 + 64 * LOADERS), smem, s, p);
     CY_LAUNCH_CHECK();
     return 0;
 }
 
 // tile capacities: 384 / 256 / 128 pixels = 4 waves over pixels x 2 over channels, 192 = 2 x 4 (BN = 128 only);
-// a 384-pixel tile leaves room for a 2-stage ring only.  variant: 0 shipped, 1 direct stores, 2 two-stage ring,
-// 3 DMA pieces issued as a burst behind the barrier instead of between the MFMAs, 5 barrier before the last sub-step
-// of a K step instead of at its top, 6 ping-pong phases (two wave groups one barrier apart).
+// a 384-pixel tile leaves room for a 2-stage ring only.  variant: 0 eight self-staging waves (3-stage ring, LDS stores),
+// 1 direct stores from the MFMA layout, 2 two-stage ring, 3 four loader + eight compute waves.
 template <typename T>
 int pipe_dispatch(const IgemmParams& p, int cap, int bn, int variant, hipStream_t s) {
 #define CY_PIPE(BM_, BN_, WN_, NST_)                                                           \
     if (cap == BM_ && bn == BN_) {                                                             \
         if (variant == 1 || (p.flags & CY_CONV_ACCUM)) return pipe_launch<T, BM_, BN_, WN_, NST_, false>(p, s); \
         if (variant == 2) return pipe_launch<T, BM_, BN_, WN_, 2, true>(p, s);                                \
+        if constexpr (NST_ == 3) { if (variant == 3) return pipe_launch<T, BM_, BN_, WN_, 3, true, 4>(p, s); } \
         return pipe_launch<T, BM_, BN_, WN_, NST_, true>(p, s);                                               \
     }
     CY_PIPE(384, 128, 2, 2) CY_PIPE(256, 128, 2, 3) CY_PIPE(192, 128, 4, 3) CY_PIPE(128, 128, 2, 3)
@@ -494,7 +543,7 @@ static bool pipe_policy(int M, int OC, int only_cap, int& cap, int& bn, int& bm_
 
 // Launches the pipelined kernel when the shape qualifies (*used = 1), else leaves the launch to conv_igemm.hip.
 // Which launches take it: the CY_CONV_TILE hint of the call (1: never, 2-5: capacity 128 / 192 / 256 / 384, 6: policy
-// tile); without a hint the eval-mode epilogue always does (its LDS-transposed stores are worth 1.3-2x on every shape of
+// tile, 7-9: capacity 128 / 192 / 256 with the loader / compute wave split); without a hint the eval-mode epilogue always does (its LDS-transposed stores are worth 1.3-2x on every shape of
 // complex_yolov4.cfg), training launches stay on the 4-wave kernels: measured per layer the two families are within
 // +-10 % of each other with the winner depending on how the tiles quantise over 256 CUs, so the engine times both once
 // per layer shape and passes the hint (models/engine.py).
@@ -511,15 +560,17 @@ int cy_pipe_try(const cyk::IgemmParams& p0, int dtype, hipStream_t s, int* used)
     if (((uintptr_t)p0.o & 15) || (p0.res && (p0.ldres % 4 || ((uintptr_t)p0.res & 7)))) return 0;
     if ((size_t)p0.N * p0.OH * p0.OW * p0.ldo * 2 >= 0xFFFFFF00ull) return 0;      // 32-bit output row offsets
     cyk::IgemmParams p = p0;
-    static const int hint_cap[] = {0, 0, 128, 192, 256, 384, 0};
-    int only = hint >= 2 && hint <= 5 ? hint_cap[hint] : 0;
+    static const int hint_cap[] = {0, 0, 128, 192, 256, 384, 0, 128, 192, 256};
+    int only = (hint >= 2 && hint <= 5) || (hint >= 7 && hint <= 9) ? hint_cap[hint] : 0;
+    const bool split = hint >= 7 && hint <= 9;       // four loader waves + eight compute waves
     if (only == 192 && p.OC <= 64) only = 256;
     int cap = 0, bn = 0, eff = 0;
     if (!pipe_policy(p.M, p.OC, only, cap, bn, eff)) return 0;
     if (g_pipe_cap) { cap = g_pipe_cap; bn = g_pipe_bn; eff = g_pipe_bm_eff ? g_pipe_bm_eff : cap; }
     if (eff > cap) return CY_ERR_ARG;
     p.bm_eff = eff;
-    const int rc = dtype == CY_F16 ? pipe_dispatch<f16>(p, cap, bn, g_pipe_variant, s) : pipe_dispatch<bf16>(p, cap, bn, g_pipe_variant, s);
+    const int variant = (split && cap <= 256) ? 3 : g_pipe_variant;
+    const int rc = dtype == CY_F16 ? pipe_dispatch<f16>(p, cap, bn, variant, s) : pipe_dispatch<bf16>(p, cap, bn, variant, s);
     if (rc == 0) { *used = 1; ++g_pipe_launches; }
     return rc;
 }

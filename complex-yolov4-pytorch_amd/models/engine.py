@@ -380,7 +380,7 @@ class Engine:
             return best
         hints = [1]
         if cin % 64 == 0 and cout % 8 == 0:
-            hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h == 3 and cout <= 64)]
+            hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h in (3, 8) and cout <= 64)]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best, best_t = 1, None
         for h in hints:

@@ -316,7 +316,8 @@ def bn_scratch_rows():
 
 
 CONV_TILE_SHIFT = 8
-CONV_TILE_HINTS = (1, 2, 3, 4, 5, 6)     # 1: 4-wave kernels; 2-5: pipelined kernel, 128/192/256/384-pixel tile; 6: its own policy
+CONV_TILE_HINTS = (1, 2, 3, 4, 5, 6, 7, 8, 9)   # 1: 4-wave kernels; 2-5: pipelined kernel, 128/192/256/384-pixel tile; 6: its own
+#                                                policy; 7-9: its loader/compute split with a 128/192/256-pixel tile
 
 
 def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None, tile=0):

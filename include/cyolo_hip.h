@@ -107,7 +107,8 @@ int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dt
  *        CY_CONV_ACCUM       -> out += result (gradient fan-in of routes / shortcuts)
  *        CY_CONV_TILE(h)     -> which kernel runs the call (results are the same; a caller that launches the same shape
  *                               every step times the candidates once): 0 library default, 1 the 4-wave kernels, 2-5 the
- *                               8-wave pipelined kernel with a 128 / 192 / 256 / 384-pixel tile, 6 with its own tile policy
+ *                               8-wave pipelined kernel with a 128 / 192 / 256 / 384-pixel tile, 6 with its own tile policy,
+ *                               7-9 its loader / compute split (4 + 8 waves) with a 128 / 192 / 256-pixel tile
  *                               (the hint is ignored where that kernel does not apply: f32, first layers, fp32 output)
  * Returns the number of stats rows written through *stats_rows when non-NULL. */
 int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out, int OH,
@@ -127,7 +128,8 @@ int64_t cy_pipe_launches(void);
 /* Test / tool switch, not used on the step path.  mode 0: never use the pipelined kernel, 1: default (hints and the
  * eval-mode epilogue select it), 2: every launch that qualifies; cap x bn (0 x 0 = policy) forces a tile capacity out of
  * {384,256,192,128} x 128 / {384,256,128} x 64 with bm_eff (0 = cap) pixels of it used; variant 0: shipped (3-stage ring,
- * LDS-transposed stores), 1: direct stores from the MFMA layout (what CY_CONV_ACCUM launches use), 2: 2-stage ring.
+ * LDS-transposed stores), 1: direct stores from the MFMA layout (what CY_CONV_ACCUM launches use), 2: 2-stage ring,
+ * 3: four loader waves + eight compute waves.
  * CY_CONV_PIPE=0 in the environment = mode 0. */
 int cy_conv_pipe_config(int mode, int cap, int bn, int variant, int bm_eff);
 

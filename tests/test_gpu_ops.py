@@ -105,7 +105,7 @@ def pipe_policy():
 
 
 @pytest.mark.parametrize('dt', [CY_F16, CY_BF16])
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 5, 6])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 @pytest.mark.parametrize('case', PIPE_CASES)
 def test_conv_pipe_forward_dgrad(dt, variant, case, pipe_policy):
     """conv_pipe.hip (8 waves, 3-stage counted-vmcnt ring, 32x32x16 MFMA, LDS-transposed stores) against torch conv2d in
@@ -114,6 +114,8 @@ def test_conv_pipe_forward_dgrad(dt, variant, case, pipe_policy):
     N, Ci, H, W, Co, ks, st, tile = case
     if variant and tile is None:
         pytest.skip('variants are swept on forced tiles')
+    if variant == 3 and tile[0] == 384:
+        pytest.skip('loader / compute split needs the 3-stage ring (capacity <= 256)')
     pad = (ks - 1) // 2
     cfg = dict(mode=2, variant=variant)
     if tile:

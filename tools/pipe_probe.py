@@ -21,11 +21,12 @@ SHAPES = [(128, 128, 3, 1, 76), (128, 256, 3, 1, 76), (256, 256, 3, 1, 38), (256
           (64, 64, 1, 1, 304), (128, 64, 1, 1, 304), (128, 128, 1, 1, 152), (256, 128, 1, 1, 76), (128, 128, 1, 1, 76),
           (512, 256, 1, 1, 38), (256, 256, 1, 1, 38), (1024, 512, 1, 1, 19), (2048, 512, 1, 1, 19)]
 if quick:
-    SHAPES = SHAPES[:6]
-CONFIGS = [('old', dict(mode=0)),
-           ('c192', dict(mode=2, cap=192, bn=0)), ('c256', dict(mode=2, cap=256, bn=0)),
-           ('c192/noread', dict(mode=2, cap=192, bn=0, variant=7)), ('c256/noread', dict(mode=2, cap=256, bn=0, variant=7)),
-           ('c192/mfma', dict(mode=2, cap=192, bn=0, variant=10)), ('c256/mfma', dict(mode=2, cap=256, bn=0, variant=10))]
+    SHAPES = SHAPES[:2] + SHAPES[5:6] + SHAPES[12:13]
+CONFIGS = [('old', dict(mode=0)), ('policy', dict(mode=2)),
+           ('c128', dict(mode=2, cap=128, bn=0)), ('c192', dict(mode=2, cap=192, bn=0)), ('c256', dict(mode=2, cap=256, bn=0)),
+           ('c384', dict(mode=2, cap=384, bn=0)),
+           ('c128/lc', dict(mode=2, cap=128, bn=0, variant=3)), ('c192/lc', dict(mode=2, cap=192, bn=0, variant=3)),
+           ('c256/lc', dict(mode=2, cap=256, bn=0, variant=3))]
 
 
 def timed(fn):
