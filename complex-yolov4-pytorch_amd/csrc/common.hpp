@@ -18,6 +18,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define CY_WAVE 64
+// rows of the shared-bin statistics tables (conv epilogue -> BatchNorm, BatchNorm backward sums): bin = block % CY_STAT_BINS.
+// 16 keeps the fold cheap enough to run in every consumer block's prologue (cy_bn_act_fwd_fused) at <= tiles / 16 adds per address.
+#define CY_STAT_BINS 16
 
 // hipGetLastError() is per-thread sticky state shared with every other HIP user in the process (PyTorch included):
 // clear it on entry so that a launch check only ever reports this call's own launches.

@@ -436,7 +436,7 @@ int dispatch(const IgemmParams& p, int dtype, hipStream_t s) {
 
 extern "C" int cy_conv_stats_rows(int M, int OC) {
     (void)M; (void)OC;
-    return 64;
+    return CY_STAT_BINS;
 }
 
 // CY_CONV_STATS_DET: one table row per pixel tile; no kernel uses tiles of fewer than 64 pixels

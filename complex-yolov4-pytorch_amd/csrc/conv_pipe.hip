@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
             }
         }
         __syncthreads();
-        float* srow = p.stats + (size_t)(p.stat_det ? tm : (lid & 63)) * 2 * p.OC;
+        float* srow = p.stats + (size_t)(p.stat_det ? tm : (lid & (CY_STAT_BINS - 1))) * 2 * p.OC;
         for (int c = tid; c < 2 * BN; c += 512) {
             const int mom = c / BN, cl = c - mom * BN, co = tn * BN + cl;
             float t = 0.f;

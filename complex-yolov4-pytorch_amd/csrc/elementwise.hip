@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
         const int i = o % CH, which = (o / CH) & 1, ck = o / (2 * CH);
         float s = 0.f;
         for (int r = 0; r < rpp; ++r) s += red[((r * cpr + ck) * 2 + which) * CH + i];
-        atomicAdd(&part[((size_t)(det ? blockIdx.x : (blockIdx.x & 63)) * 2 + which) * C + ck * CH + i], s);
+        atomicAdd(&part[((size_t)(det ? blockIdx.x : (blockIdx.x & (CY_STAT_BINS - 1))) * 2 + which) * C + ck * CH + i], s);
     }
 }
 
@@ -137,9 +137,177 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// ---- fused finalisers ------------------------------------------------------------------------------------------
+// The statistics fold (cy_bn_finalize / cy_bn_bwd_finalize: 214 launches of ~5 us per step, each a dependent kernel
+// boundary on the critical path) moved into the prologue of the kernel that consumes its result.  A block covers a group
+// of CG <= 128 channels (grid.y) and a range of pixels (grid.x), so its fold is CY_STAT_BINS x 2 x CG floats (<= 16 KB from
+// L2).  The first pixel block of every channel group also writes what the finaliser used to write (mean / invstd / scale /
+// shift and the running statistics; the parameter gradients in the backward kernel).  The table cannot be zeroed by the
+// kernel that reads it (other blocks may still be reading), so two tables alternate from one BatchNorm layer to the next
+// and every launch zeroes the OTHER one (last read by the previous layer's kernel, next written by the following conv).
+struct BnFoldParams {
+    const float* bins;       // [CY_STAT_BINS][2][C]
+    float* zero_table;       // the other table of the pair
+    int zero_n;
+    double count;
+    const float* gamma;
+    const float* beta;
+    float* rmean;
+    float* rvar;
+    long long* nbt;
+    float momentum, eps;
+    float* vec;              // [4][C]: mean, invstd, scale, shift
+};
+
+__device__ __forceinline__ void zero_other_table(float* t, int n) {
+    const int nthreads = gridDim.x * gridDim.y * blockDim.x;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += nthreads) t[i] = 0.f;
+}
+
+template <typename T, int ACT, bool RES>
+__global__ void __launch_bounds__(256) bn_act_fwd_fused_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                              const T* __restrict__ res, int ldres, long M, int C, int CG,
+                                                              BnFoldParams f, int ppb) {
+    constexpr int CH = Elem<T>::CH;
+    __shared__ float s_sc[128], s_sh[128];
+    const int c0 = blockIdx.y * CG;
+    // fold: thread t < CG owns channel c0 + t; bins in index order, double accumulation (what cy_bn_finalize does)
+    if ((int)threadIdx.x < CG) {
+        const int c = c0 + threadIdx.x;
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int b = 0; b < CY_STAT_BINS; ++b) {
+            s += (double)f.bins[((size_t)b * 2) * C + c];
+            q += (double)f.bins[((size_t)b * 2 + 1) * C + c];
+        }
+        const double m = s / f.count;
+        double var = q / f.count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float sc = f.gamma[c] * is;
+        const float sh = f.beta[c] - (float)m * sc;
+        s_sc[threadIdx.x] = sc;
+        s_sh[threadIdx.x] = sh;
+        if (blockIdx.x == 0) {
+            f.vec[c] = (float)m;
+            f.vec[C + c] = is;
+            f.vec[2 * C + c] = sc;
+            f.vec[3 * C + c] = sh;
+            if (f.rmean) {
+                const double unb = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+                f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * (float)m;
+                f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * (float)unb;
+            }
+            if (f.nbt && c == 0) *f.nbt += 1;
+        }
+    }
+    zero_other_table(f.zero_table, f.zero_n);
+    __syncthreads();
+    const int cpr = CG / CH, rpp = 256 / cpr;
+    const int chunk = threadIdx.x % cpr, row = threadIdx.x / cpr;
+    float sc[CH], sh[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { sc[i] = s_sc[chunk * CH + i]; sh[i] = s_sh[chunk * CH + i]; }
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < M ? p0 + ppb : M;
+    const int cc = c0 + chunk * CH;
+    for (long p = p0 + row; p < p1; p += rpp) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + p * ldx + cc);
+        float fv[CH];
+        chunk_to_f32<T>(v, fv);
+        float r[CH];
+        if (RES) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(res + p * ldres + cc);
+            chunk_to_f32<T>(rv, r);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            fv[i] = act_f<ACT, sizeof(T) == 2>(fv[i] * sc[i] + sh[i]);
+            if (RES) fv[i] += r[i];
+        }
+        *reinterpret_cast<u32x4*>(y + p * ldy + cc) = f32_to_chunk<T>(fv);
+    }
+}
+
+struct BnBwdFoldParams {
+    const float* bins;       // [CY_STAT_BINS][2][C]: sum dz, sum dz * xhat
+    float* zero_table;
+    int zero_n;
+    float* ggamma;
+    float* gbeta;
+    float gscale;
+};
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_apply_fused_kernel(const T* __restrict__ x, int ldx, const T* dy, int lddy, T* dx,
+                                                                int lddx, T* resg, int ldrg, int res_accum, long M, int C,
+                                                                int CG, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, BnBwdFoldParams f, int ppb) {
+    constexpr int CH = Elem<T>::CH;
+    __shared__ float s_dg[128], s_db[128];
+    const int c0 = blockIdx.y * CG;
+    if ((int)threadIdx.x < CG) {
+        const int c = c0 + threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < CY_STAT_BINS; ++b) {
+            s1 += (double)f.bins[((size_t)b * 2) * C + c];
+            s2 += (double)f.bins[((size_t)b * 2 + 1) * C + c];
+        }
+        s_db[threadIdx.x] = (float)s1;
+        s_dg[threadIdx.x] = (float)s2;
+        if (blockIdx.x == 0) {
+            if (f.gbeta) f.gbeta[c] += f.gscale * (float)s1;
+            if (f.ggamma) f.ggamma[c] += f.gscale * (float)s2;
+        }
+    }
+    zero_other_table(f.zero_table, f.zero_n);
+    __syncthreads();
+    const int cpr = CG / CH, rpp = 256 / cpr;
+    const int chunk = threadIdx.x % cpr, row = threadIdx.x / cpr;
+    const float invM = 1.f / (float)M;
+    float sc[CH], sh[CH], mu[CH], is[CH], mg[CH], mb[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = c0 + chunk * CH + i;
+        sc[i] = scale[c]; sh[i] = shift[c]; mu[i] = mean[c]; is[i] = invstd[c];
+        mg[i] = s_dg[chunk * CH + i] * invM; mb[i] = s_db[chunk * CH + i] * invM;
+    }
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < M ? p0 + ppb : M;
+    const int cc = c0 + chunk * CH;
+    for (long p = p0 + row; p < p1; p += rpp) {
+        float fv[CH], g[CH];
+        chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(x + p * ldx + cc), fv);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + p * lddy + cc);
+        chunk_to_f32<T>(gv, g);
+        if (resg) {
+            if (res_accum) {
+                float o[CH];
+                chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(resg + p * ldrg + cc), o);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) o[i] += g[i];
+                *reinterpret_cast<u32x4*>(resg + p * ldrg + cc) = f32_to_chunk<T>(o);
+            } else {
+                *reinterpret_cast<u32x4*>(resg + p * ldrg + cc) = gv;
+            }
+        }
+        float o[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const float dz = g[i] * act_grad<ACT, sizeof(T) == 2>(fv[i] * sc[i] + sh[i]);
+            const float xh = (fv[i] - mu[i]) * is[i];
+            o[i] = sc[i] * (dz - mb[i] - xh * mg[i]);
+        }
+        *reinterpret_cast<u32x4*>(dx + p * lddx + cc) = f32_to_chunk<T>(o);
+    }
+}
+
 // finish: one wave per channel, lane k owns bin k of the [64][2][C] fp32 table (filled with atomics by the conv
 // epilogue / the backward reduce); the lane that read a bin zeroes it, so the table is clean for its next user.
-constexpr int CY_BINS = 64;
+constexpr int CY_BINS = CY_STAT_BINS;
 __global__ void __launch_bounds__(256) bn_finalize_kernel(float* __restrict__ bins, int rows, int C, double count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* rmean, float* rvar, long long* nbt, float momentum,
@@ -689,6 +857,83 @@ extern "C" int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const voi
     CY_DT_SWITCH(dtype, CY_BNF_ACT)
 #undef CY_BNF
 #undef CY_BNF_ACT
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+// channel group / pixels per block of the fused kernels: CG <= 128 channels with 256 / (CG / ch) rows per pass
+static inline int fused_cg(int C, int ch) {
+    int cg = C < 128 ? C : 128;
+    while (C % cg || 256 % (cg / ch)) cg /= 2;
+    return cg;
+}
+
+extern "C" int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
+                                   const float* stats_bins, int rows, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                   float eps, float* vec_out, float* zero_table, int zero_n, int act, int dtype,
+                                   cy_stream_t s) {
+    CY_ENTER();
+    const int ch = dtype == CY_F32 ? 4 : 8;
+    if (!x || !y || !stats_bins || !gamma || !beta || !vec_out || rows != CY_BINS || M < 1 || C % ch || ldx % ch || ldy % ch ||
+        (res && ldres % ch) || (zero_n > 0 && !zero_table) || zero_table == stats_bins)
+        return CY_ERR_ARG;
+    const int cg = fused_cg(C, ch);
+    if (cg < ch || cg > 128) return CY_ERR_ARG;
+    const int rpp = 256 / (cg / ch);
+    long ppb = (M + 1023) / 1024;                 // ~1024 pixel blocks x C / CG channel groups
+    if (ppb < 4L * rpp) ppb = 4L * rpp;
+    ppb = (ppb + rpp - 1) / rpp * rpp;
+    const dim3 grid((unsigned)((M + ppb - 1) / ppb), (unsigned)(C / cg));
+    BnFoldParams f;
+    f.bins = stats_bins; f.zero_table = zero_table; f.zero_n = zero_n; f.count = (double)M; f.gamma = gamma; f.beta = beta;
+    f.rmean = running_mean; f.rvar = running_var; f.nbt = (long long*)num_batches_tracked; f.momentum = momentum; f.eps = eps;
+    f.vec = vec_out;
+#define CY_BNFF(T, A)                                                                                                  \
+    if (res) hipLaunchKernelGGL((bn_act_fwd_fused_kernel<T, A, true>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (T*)y, \
+                                ldy, (const T*)res, ldres, (long)M, C, cg, f, (int)ppb);                                \
+    else hipLaunchKernelGGL((bn_act_fwd_fused_kernel<T, A, false>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (T*)y,  \
+                            ldy, (const T*)nullptr, 0, (long)M, C, cg, f, (int)ppb);
+#define CY_BNFF_ACT(T)                                        \
+    if (act == CY_ACT_MISH) { CY_BNFF(T, CY_ACT_MISH) }       \
+    else if (act == CY_ACT_LEAKY) { CY_BNFF(T, CY_ACT_LEAKY) } \
+    else { CY_BNFF(T, CY_ACT_LINEAR) }
+    CY_DT_SWITCH(dtype, CY_BNFF_ACT)
+#undef CY_BNFF
+#undef CY_BNFF_ACT
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_bn_act_bwd_apply_fused(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, void* res_grad,
+                                         int ldrg, int res_accum, int64_t M, int C, const float* mean, const float* invstd,
+                                         const float* scale, const float* shift, const float* part_bins, int rows,
+                                         float* ggamma, float* gbeta, float gscale, float* zero_table, int zero_n, int act,
+                                         int dtype, cy_stream_t s) {
+    CY_ENTER();
+    const int ch = dtype == CY_F32 ? 4 : 8;
+    if (!x || !dy || !dx || !part_bins || !mean || !invstd || !scale || !shift || rows != CY_BINS || M < 1 || C % ch || ldx % ch ||
+        lddy % ch || lddx % ch || (res_grad && ldrg % ch) || (zero_n > 0 && !zero_table) || zero_table == part_bins)
+        return CY_ERR_ARG;
+    const int cg = fused_cg(C, ch);
+    if (cg < ch || cg > 128) return CY_ERR_ARG;
+    const int rpp = 256 / (cg / ch);
+    long ppb = (M + 1023) / 1024;
+    if (ppb < 4L * rpp) ppb = 4L * rpp;
+    ppb = (ppb + rpp - 1) / rpp * rpp;
+    const dim3 grid((unsigned)((M + ppb - 1) / ppb), (unsigned)(C / cg));
+    BnBwdFoldParams f;
+    f.bins = part_bins; f.zero_table = zero_table; f.zero_n = zero_n; f.ggamma = ggamma; f.gbeta = gbeta; f.gscale = gscale;
+#define CY_BNAF(T, A)                                                                                                 \
+    hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<T, A>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (const T*)dy, lddy, \
+                       (T*)dx, lddx, (T*)res_grad, ldrg, res_accum, (long)M, C, cg, mean, invstd, scale, shift, f, (int)ppb);
+#define CY_BNAF_ACT(T)                                        \
+    if (act == CY_ACT_MISH) { CY_BNAF(T, CY_ACT_MISH) }       \
+    else if (act == CY_ACT_LEAKY) { CY_BNAF(T, CY_ACT_LEAKY) } \
+    else { CY_BNAF(T, CY_ACT_LINEAR) }
+    CY_DT_SWITCH(dtype, CY_BNAF_ACT)
+#undef CY_BNAF
+#undef CY_BNAF_ACT
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -34,7 +34,7 @@ struct IgemmParams {
     int act, ldres;
     unsigned x_bias;              // fast / pipelined kernels: bytes the gather descriptor's base sits below g (>= any negative row offset)
     int bm_eff;                   // conv_pipe.hip: pixels per tile actually used (<= the kernel's tile capacity)
-    int stat_det;                 // statistics table: 0 = 64 bins shared by the blocks (atomics, bin = tile % 64);
+    int stat_det;                 // statistics table: 0 = CY_STAT_BINS bins shared by the blocks (atomics, bin = tile % CY_STAT_BINS);
                                   // 1 = one row per pixel tile (one add per address onto zero: run-to-run deterministic)
 };
 
@@ -136,7 +136,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             }
         }
         __syncthreads();
-        float* srow = p.stats + (size_t)(p.stat_det ? tm : (lid & 63)) * 2 * p.OC;
+        float* srow = p.stats + (size_t)(p.stat_det ? tm : (lid & (CY_STAT_BINS - 1))) * 2 * p.OC;
         for (int c = tid; c < 2 * BN; c += NT) {
             const int mom = c / BN, cl = c - mom * BN, co = tn * BN + cl;
             float t = 0.f;

@@ -82,6 +82,13 @@ class Engine:
         # binned-atomics tables: zero once, every finaliser leaves its table zeroed for the next layer
         self.stats = torch.zeros(max_stats, **f32)
         self.bnpart = torch.zeros(max_bnrows, **f32)
+        # default (non-deterministic) mode: the fold runs in the prologue of the consuming kernel (cy_bn_act_fwd_fused /
+        # cy_bn_act_bwd_apply_fused), which cannot zero the table it reads -- two tables alternate from layer to layer and
+        # every launch zeroes the other one
+        self.fused_bn = not self.det and hasattr(ops, 'bn_act_fwd_fused') and os.environ.get('CY_FUSED_BN', '1') != '0'
+        self.stats_pair = [self.stats, torch.zeros(max_stats, **f32)] if self.fused_bn else None
+        self.bnpart_pair = [self.bnpart, torch.zeros(max_bnrows, **f32)] if (self.fused_bn and training) else None
+        self._sp = self._bp = 0
         self.dgs, self.dbs = torch.empty(max_c, **f32), torch.empty(max_c, **f32)
         # split-K slabs of every conv stay resident until their group is folded (table-driven, a few launches per step)
         self.wpart = torch.empty(max(max_wpart, 1), **f32)
@@ -229,6 +236,17 @@ class Engine:
         vec = self.bnvec[idx]
         mean, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3]
         C, M = rec['cout'], raw.M
+        if self.training and self.fused_bn:
+            tbl, other = self.stats_pair[self._sp], self.stats_pair[self._sp ^ 1]
+            self._sp ^= 1
+            with ops.prof('igemm', *self._conv_work(rec)):
+                ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=CONV_STATS, stats=tbl,
+                               tile=self._fwd_tile.get(idx, 0))
+            res = self.view(rec['res']) if rec['res'] is not None else None
+            ops.bn_act_fwd_fused(raw, self.view(rec['out']), res, tbl, ops.conv_stats_rows(M, C), P[bname + '.weight'],
+                                 P[bname + '.bias'], P[bname + '.running_mean'], P[bname + '.running_var'],
+                                 P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, vec, other, ops.ACT[rec['act']])
+            return
         if self.training:
             with ops.prof('igemm', *self._conv_work(rec)):
                 ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=self._stat_flags,
@@ -420,6 +438,8 @@ class Engine:
                     xv, self.wf[idx], cop, out, rec['ks'], rec['stride'], rec['pad'], vec[2], vec[3], ops.ACT[rec['act']], res,
                     tile=h), xv.C, out.C)
         self.stats.zero_()        # the timed launches added into the statistics table
+        if self.stats_pair is not None:
+            self.stats_pair[1].zero_()
 
     def _autotune_dgrad(self):
         self._dgrad_tuned = True
@@ -486,9 +506,14 @@ class Engine:
         C, M = rec['cout'], raw.M
         act = ops.ACT[rec['act']]
         rows = ops.bn_bwd_rows(M, C, self.dt, self.det)
-        ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, self.bnpart, rows)
-        ops.bn_bwd_finalize(self.bnpart, rows, C, self.dgs, self.dbs,
-                            self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls)
+        if self.fused_bn:
+            tbl, other = self.bnpart_pair[self._bp], self.bnpart_pair[self._bp ^ 1]
+            self._bp ^= 1
+            ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, tbl, rows)
+        else:
+            ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, self.bnpart, rows)
+            ops.bn_bwd_finalize(self.bnpart, rows, C, self.dgs, self.dbs,
+                                self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls)
         res_view, res_acc = None, False
         runs = b['res_runs']
         if len(runs) == 1:
@@ -497,7 +522,11 @@ class Engine:
             res = rec['res']
             for ref, acc in runs:
                 ops.slice_copy(g.channels(ref.c0 - res.c0, ref.C), self.view(ref, grad=True), accumulate=acc)
-        ops.bn_act_bwd_apply(raw, g, g, res_view, res_acc, mean, invstd, scale, shift, self.dgs, self.dbs, act)
+        if self.fused_bn:
+            ops.bn_act_bwd_apply_fused(raw, g, g, res_view, res_acc, mean, invstd, scale, shift, tbl, rows,
+                                       self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls, other, act)
+        else:
+            ops.bn_act_bwd_apply(raw, g, g, res_view, res_acc, mean, invstd, scale, shift, self.dgs, self.dbs, act)
         self._wgrad(rec, g, self.view(rec['x']))
         self._dgrad(rec, g, b['dx'])
 

@@ -133,7 +133,7 @@ int64_t cy_pipe_launches(void);
  * CY_CONV_PIPE=0 in the environment = mode 0. */
 int cy_conv_pipe_config(int mode, int cap, int bn, int variant, int bm_eff);
 
-/* Number of rows (bins) of the stats table cy_conv_igemm adds into (64). */
+/* Number of rows (bins) of the stats table cy_conv_igemm adds into (16). */
 int cy_conv_stats_rows(int M, int OC);
 /* With CY_CONV_STATS | CY_CONV_STATS_DET every pixel tile adds into its OWN row (one add per address onto zero: the
  * table, and everything computed from it, is bit-identical from run to run -- fp32 atomics into shared bins are not).
@@ -167,6 +167,21 @@ int cy_bn_eval_affine(const float* gamma, const float* beta, const float* runnin
  * darknet2pytorch.py:208-219) in one pass.  x: (M pixels, C, ldx); y: ldy; res may be NULL. */
 int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
                   const float* scale, const float* shift, int act, int dtype, cy_stream_t s);
+/* cy_bn_finalize + cy_bn_act_fwd in ONE launch (the training forward path; cy_bn_finalize stays for the deterministic
+ * mode, whose per-tile tables are too long to fold in every block): every block folds the CY_STAT_BINS-row table of its
+ * channel group in its prologue, the first pixel block of a group writes vec_out[4][C] = (mean, invstd, scale, shift) and
+ * updates the running statistics, and the launch zeroes zero_table[0:zero_n] -- the OTHER table of an alternating pair
+ * (the one this kernel reads is left as it is: it is zeroed by the next layer's launch). */
+int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
+                        const float* stats_bins, int rows, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* vec_out,
+                        float* zero_table, int zero_n, int act, int dtype, cy_stream_t s);
+/* cy_bn_bwd_finalize + cy_bn_act_bwd_apply in one launch, same scheme: ggamma / gbeta += gscale * sums by the first pixel
+ * block of every channel group. */
+int cy_bn_act_bwd_apply_fused(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, void* res_grad, int ldrg,
+                              int res_accum, int64_t M, int C, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, const float* part_bins, int rows, float* ggamma, float* gbeta,
+                              float gscale, float* zero_table, int zero_n, int act, int dtype, cy_stream_t s);
 /* Backward pass 1: per-channel partial sums of dz and dz*xhat, dz = dy*act'(x*scale+shift), ADDED (fp32 atomics) into
  * part[row][2][C]; zero on entry, cy_bn_bwd_finalize(rows) folds it and leaves it zeroed.  rows = cy_bn_bwd_rows()
  * (64 bins shared by the blocks) or cy_bn_bwd_rows_det() (one row per block: run-to-run deterministic). */

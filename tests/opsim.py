@@ -154,6 +154,26 @@ def bn_act_fwd(x, y, res, scale, shift, act):
     _store(y, a)
 
 
+def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momentum, eps, vec, zero_table, act):
+    C = x.C
+    st = bins.view(-1)[:rows * 2 * C].clone()
+    bn_finalize(st, rows, C, x.M, gamma, beta, rmean, rvar, nbt, momentum, eps, vec[0], vec[1], vec[2], vec[3])
+    if zero_table is not None:
+        zero_table.zero_()
+    bn_act_fwd(x, y, res, vec[2], vec[3], act)
+
+
+def bn_act_bwd_apply_fused(x, dy, dx, res_grad, res_accum, mean, invstd, scale, shift, bins, rows, ggamma, gbeta, gscale,
+                           zero_table, act):
+    C = x.C
+    dgs, dbs = torch.zeros(C), torch.zeros(C)
+    st = bins.view(-1)[:rows * 2 * C].clone()
+    bn_bwd_finalize(st, rows, C, dgs, dbs, ggamma, gbeta, gscale)
+    if zero_table is not None:
+        zero_table.zero_()
+    bn_act_bwd_apply(x, dy, dx, res_grad, res_accum, mean, invstd, scale, shift, dgs, dbs, act)
+
+
 def _dz(x, dy, scale, shift, act):
     with torch.enable_grad():
         z = (_nchw(x) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).detach().requires_grad_(True)
@@ -280,7 +300,7 @@ def yolo_loss(logits, B, G, A, C, targets, anchors, img_size, ignore_thresh, use
 
 NAMES = ['check_device_tensor', 'nchw_to_nhwc', 'pack_weights_into', 'make_pack_table', 'pack_weights_multi',
          'make_reduce_table', 'wgrad_reduce_multi', 'conv_bn_act_eval', 'conv_igemm', 'conv_wgrad', 'wgrad_reduce',
-         'bn_finalize', 'bn_eval_affine', 'bn_act_fwd', 'bn_act_bwd_reduce', 'bn_bwd_finalize', 'bn_act_bwd_apply',
+         'bn_finalize', 'bn_eval_affine', 'bn_act_fwd', 'bn_act_fwd_fused', 'bn_act_bwd_apply_fused', 'bn_act_bwd_reduce', 'bn_bwd_finalize', 'bn_act_bwd_apply',
          'maxpool_argmax_bytes', 'maxpool_fwd', 'maxpool_bwd', 'upsample_fwd', 'upsample_bwd', 'slice_copy', 'slice_add', 'f32_to_view',
          'zero_view', 'bias_grad', 'yolo_decode', 'yolo_loss']
 

@@ -35,7 +35,7 @@ def test_host_only_entry_points(built):
     assert lib.raw('cy_conv_wgrad_split')(16 * 76 * 76, 128, 128, 3) >= 1
     assert lib.raw('cy_yolo_loss_workspace')(16, 76, 3, 3, 96) > 16 * 3 * 76 * 76 * 8
     assert lib.raw('cy_rnms_workspace')(32, 256) > 0
-    assert lib.raw('cy_bn_scratch_rows')() >= 0 and lib.raw('cy_bn_bwd_rows')(1000, 64, 0) == 64
+    assert lib.raw('cy_bn_scratch_rows')() >= 0 and lib.raw('cy_bn_bwd_rows')(1000, 64, 0) == lib.raw('cy_conv_stats_rows')(1000, 64) == 16
 
 
 def test_argument_validation_without_launch(built):
