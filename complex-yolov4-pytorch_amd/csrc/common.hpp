@@ -135,6 +135,13 @@ __device__ __forceinline__ float mish_grad(float x) {
     if (x > 20.f) return 1.f;
     const float n = cy_exp<FAST>(x);
     const float w = n * (n + 2.f);
+    if (FAST) {
+        // one reciprocal instead of two divisions: with v = w + 2,  tanh(softplus) = w / v,  1 - t^2 = 4 (n + 1)^2 / v^2,
+        // sigmoid = n / (n + 1)  =>  mish' = (w v + 4 x n (n + 1)) / v^2   (v^2 <= 5e34 for x <= 20: no overflow).
+        // The backward reduce pass is VALU-bound on this function.
+        const float v = w + 2.f;
+        return (w * v + 4.f * x * n * (n + 1.f)) * __builtin_amdgcn_rcpf(v * v);
+    }
     const float t = cy_div<FAST>(w, w + 2.f);    // tanh(softplus(x))
     const float sg = cy_div<FAST>(n, 1.f + n);   // sigmoid(x)
     return t + x * (1.f - t * t) * sg;
