@@ -512,39 +512,65 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// table-driven fold: block -> (descriptor, first output element); 256 threads = 4 groups of 64 consecutive outputs,
-// each thread walks all slabs of its output (coalesced 256-byte reads per wave and slab).  A thread-per-(co, ci)
-// variant with contiguous OIHW writes (the scatter below writes 4 bytes every ks*ks floats) was measured 1.36x SLOWER:
-// nine times fewer threads, each with a serial chain of slab loads.
+// table-driven fold: block -> (descriptor, first (co, ci) pair / 256); one thread per (co, ci) pair walks all slabs of its
+// ks*ks taps (consecutive threads = consecutive ci: 256-byte reads per wave, tap and slab), then the block transposes its
+// [256 pairs][kk] sums through LDS so that the OIHW gradient -- 4 bytes every kk floats from a pair's point of view -- is
+// read and written as ONE contiguous run of 256*kk floats.  The earlier thread-per-output version scattered 4-byte
+// writes at a 36-byte stride: rocprofv3 counted 1.75 GB of HBM traffic per launch against 0.87 GB of slabs (DESIGN.md
+// section 9, PMC table).
+template <int KK>
+__device__ __forceinline__ void fold_pairs(const cy_reduce_desc& d, long first_pair, float scale, int accumulate,
+                                           float* lds) {
+    const long npairs = (long)d.Co * d.Ci;
+    const int ncols = KK * d.CiPad;
+    const size_t slab = (size_t)d.CoRows * ncols;
+    const long p = first_pair + threadIdx.x;
+    float acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+    if (p < npairs) {
+        const int ci = (int)(p % d.Ci), co = (int)(p / d.Ci);
+        const float* src = d.part + (size_t)co * ncols + ci;
+        for (int sp = 0; sp < d.split; ++sp) {
+#pragma unroll
+            for (int t = 0; t < KK; ++t) acc[t] += src[(size_t)sp * slab + t * d.CiPad];
+        }
+    }
+    if (KK == 1) {
+        if (p < npairs) d.grad[p] = scale * acc[0] + (accumulate ? d.grad[p] : 0.f);
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < KK; ++t) lds[threadIdx.x * KK + t] = acc[t];
+    __syncthreads();
+    const long total = npairs * KK, o0 = first_pair * KK;
+#pragma unroll
+    for (int i = 0; i < KK; ++i) {
+        const int o = i * 256 + threadIdx.x;
+        if (o0 + o < total) d.grad[o0 + o] = scale * lds[o] + (accumulate ? d.grad[o0 + o] : 0.f);
+    }
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const cy_reduce_desc* __restrict__ desc,
                                                                 const int* __restrict__ blocks, float scale,
                                                                 int accumulate) {
+    __shared__ float lds[256 * 9];
     const cy_reduce_desc d = desc[blocks[2 * blockIdx.x]];
     const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
-    const int kk = d.ks * d.ks;
-    const long total = (long)d.Co * kk * d.Ci;
-    const int ncols = kk * d.CiPad;
-    const size_t slab = (size_t)d.CoRows * ncols;
-#pragma unroll
-    for (int it = 0; it < CY_MULTI_ELEMS / 256; ++it) {
-        const long idx = first + it * 256 + threadIdx.x;
-        if (idx >= total) break;
-        const int ci = (int)(idx % d.Ci);
-        const long t = idx / d.Ci;
-        const int tap = (int)(t % kk), co = (int)(t / kk);
-        const float* src = d.part + (size_t)co * ncols + tap * d.CiPad + ci;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int sp = 0;
-        for (; sp + 3 < d.split; sp += 4) {
-            s0 += src[(size_t)sp * slab];
-            s1 += src[(size_t)(sp + 1) * slab];
-            s2 += src[(size_t)(sp + 2) * slab];
-            s3 += src[(size_t)(sp + 3) * slab];
+    if (d.ks == 1) fold_pairs<1>(d, first, scale, accumulate, lds);
+    else if (d.ks == 3) fold_pairs<9>(d, first, scale, accumulate, lds);
+    else {   // other kernel sizes: one pair per thread, strided writes
+        const int kk = d.ks * d.ks;
+        const long p = first + threadIdx.x;
+        if (p >= (long)d.Co * d.Ci) return;
+        const int ci = (int)(p % d.Ci), co = (int)(p / d.Ci);
+        const int ncols = kk * d.CiPad;
+        const size_t slab = (size_t)d.CoRows * ncols;
+        for (int t = 0; t < kk; ++t) {
+            float sum = 0.f;
+            for (int sp = 0; sp < d.split; ++sp) sum += d.part[(size_t)sp * slab + (size_t)co * ncols + t * d.CiPad + ci];
+            d.grad[p * kk + t] = scale * sum + (accumulate ? d.grad[p * kk + t] : 0.f);
         }
-        for (; sp < d.split; ++sp) s0 += src[(size_t)sp * slab];
-        const size_t dst = ((size_t)co * d.Ci + ci) * kk + tap;
-        const float v = scale * ((s0 + s1) + (s2 + s3));
-        d.grad[dst] = v + (accumulate ? d.grad[dst] : 0.f);
     }
 }
 

@@ -218,11 +218,11 @@ def pack_weights_into(w, co_pad, ci_pad, dt, wf, wd):
 MULTI_ELEMS = 1024
 
 
-def _block_table(counts):
+def _block_table(counts, per_block=MULTI_ELEMS):
     """[(descriptor index, element count)] -> int32 [nblocks, 2] of (descriptor, first element / 256)."""
     rows = []
     for i, n in enumerate(counts):
-        for first in range(0, n, MULTI_ELEMS):
+        for first in range(0, n, per_block):
             rows.append((i, first // 256))
     return rows
 
@@ -251,9 +251,9 @@ def make_reduce_table(items, device):
     raw, counts = b'', []
     for part, grad, split, corows, cip, ks, Co, Ci in items:
         raw += struct.pack('<QQiiiiii', part.data_ptr(), grad.data_ptr(), split, corows, cip, ks, Co, Ci)
-        counts.append(Co * ks * ks * Ci)
+        counts.append(Co * Ci)             # the fold's unit is one (co, ci) pair with all its taps; 256 pairs per block
     desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-    blocks = torch.tensor(_block_table(counts), dtype=torch.int32, device=device)
+    blocks = torch.tensor(_block_table(counts, 256), dtype=torch.int32, device=device)
     return desc, blocks
 
 

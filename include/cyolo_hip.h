@@ -54,7 +54,8 @@ int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad, int CiPad
  * each, ~110 per step).  `desc` is a device array of cy_pack_desc / cy_reduce_desc; `blocks` a device array of
  * (descriptor index, first element / 256) pairs, one per 256-thread block covering CY_MULTI_ELEMS elements; for the
  * pack table an "element" run of CY_MULTI_ELEMS stands for one 64 x 64 (co, ci) tile of the padded weight matrix
- * (tile = second entry / 4, tiles enumerated ci-fastest, ks <= 3). */
+ * (tile = second entry / 4, tiles enumerated ci-fastest, ks <= 3); for the reduce table the unit is one (co, ci) pair
+ * with all ks*ks taps and a block covers 256 pairs (second entry = first pair / 256). */
 typedef struct {
     const float* w; void* wf; void* wd;
     int Co, Ci, ks, CoPad, CiPad, pad_;

@@ -25,19 +25,26 @@ def fam(name):
             return f
     return 'other'
 agg = collections.defaultdict(lambda: dict(launches=0, FETCH_SIZE=0.0, WRITE_SIZE=0.0))
+STEADY = 3     # the run is 2 warm-up + 3 timed steps; only dispatches after the 2nd Adam launch are counted, so the one-time
+               # tile-tuning launches of the first step do not enter the per-launch averages
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-    n = collections.Counter()
+    rows = []
     for f in glob.glob('%s/pmc_%s/**/*counter_collection.csv' % (root, c), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] != c:
-                continue
-            k = fam(r['Kernel_Name'])
-            agg[k][c] += float(r['Counter_Value'])
-            n[k] += 1
+        rows += [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == c]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    adam = [int(r['Dispatch_Id']) for r in rows if 'adam_multi' in r['Kernel_Name']]
+    assert len(adam) == 2 + STEADY, adam
+    n = collections.Counter()
+    for r in rows:
+        if int(r['Dispatch_Id']) <= adam[1]:
+            continue
+        k = fam(r['Kernel_Name'])
+        agg[k][c] += float(r['Counter_Value'])
+        n[k] += 1
     for k, v in n.items():
         agg[k]['launches'] = max(agg[k]['launches'], v)
 # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-units of 1024? -> the counters are in KB (1 KB = 1024 B) per the tool's derived metric
-out = {'kernel_sources_sha': bench.kernel_sources_sha(), 'git_head': os.environ.get('GIT_HEAD', 'unknown'),
+out = {'steps_counted': STEADY, 'kernel_sources_sha': bench.kernel_sources_sha(), 'git_head': os.environ.get('GIT_HEAD', 'unknown'),
        'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra (CY_WGRAD_AUTOTUNE=0)'}
 for k, v in sorted(agg.items()):
     L = max(1, v['launches'])
