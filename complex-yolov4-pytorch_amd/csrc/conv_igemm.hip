@@ -427,6 +427,7 @@ int dispatch(const IgemmParams& p, int dtype, hipStream_t s) {
     int used = 0;
     const int rc = cy_pipe_try(p, dtype, s, &used);
     if (rc || used) return rc;
+    if (p.flags & CY_CONV_BNBWD_SUMS) return CY_ERR_ARG;   // only the pipelined kernel has that epilogue
     if (dtype == CY_F16) return dispatch_tiles<f16>(p, s);
     if (dtype == CY_BF16) return dispatch_tiles<bf16>(p, s);
     return dispatch_tiles<float>(p, s);
@@ -448,17 +449,19 @@ extern "C" int cy_conv_stats_rows_det(int M, int OC) {
 static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out,
                            int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags,
                            const float* bias, float* stats_part, int* stats_rows_host, const float* aff_scale,
-                           const float* aff_shift, int act, const void* res, int ldres, cy_stream_t s) {
+                           const float* aff_shift, int act, const void* res, int ldres, cy_stream_t s,
+                           const float* bn_mean = nullptr, const float* bn_invstd = nullptr) {
     const int ch = dtype == CY_F32 ? 4 : 8;
     if (!g || !w || !out || (dtype != CY_F16 && dtype != CY_BF16 && dtype != CY_F32)) return CY_ERR_ARG;
     if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2) || GC % ch || ldg % ch) return CY_ERR_ARG;
     if ((flags & CY_CONV_STATS) && !stats_part) return CY_ERR_ARG;
-    if ((flags & CY_CONV_STATS_DET) && !(flags & CY_CONV_STATS)) return CY_ERR_ARG;
+    if ((flags & CY_CONV_STATS_DET) && !(flags & (CY_CONV_STATS | CY_CONV_BNBWD_SUMS))) return CY_ERR_ARG;
     if (!(flags & CY_CONV_BIAS_F32OUT) && (ldo % 4)) return CY_ERR_ARG;
     IgemmParams p;
     p.g = (const unsigned char*)g; p.w = (const unsigned char*)w; p.o = (unsigned char*)out;
     p.bias = bias; p.stats = stats_part;
     p.aff_scale = aff_scale; p.aff_shift = aff_shift; p.act = act; p.res = (const unsigned char*)res; p.ldres = ldres;
+    p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
     if ((flags & CY_CONV_AFFINE_ACT) && (!aff_scale || !aff_shift || (flags & (CY_CONV_STATS | CY_CONV_TRANSPOSED)))) return CY_ERR_ARG;
     p.N = N; p.GH = GH; p.GW = GW; p.GC = GC; p.ldg = ldg;
     p.OH = OH; p.OW = OW; p.OC = OC; p.ldo = ldo;
@@ -467,6 +470,8 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
     p.mtiles = p.ntiles = 0; p.bm_eff = 0;
     p.stat_det = (flags & CY_CONV_STATS_DET) ? 1 : 0;
     if (p.M <= 0 || OC <= 0) return CY_ERR_ARG;
+    if ((flags & CY_CONV_BNBWD_SUMS) && (!bn_mean || stride != 1 || (flags & (CY_CONV_STATS | CY_CONV_AFFINE_ACT | CY_CONV_BIAS_F32OUT))))
+        return CY_ERR_ARG;
     if (stats_rows_host) *stats_rows_host = (flags & CY_CONV_STATS_DET) ? cy_conv_stats_rows_det(p.M, OC) : cy_conv_stats_rows(p.M, OC);
     const size_t esz = dtype == CY_F32 ? 4 : 2;
     const size_t gb = (((size_t)N * GH * GW - 1) * ldg + GC) * esz, wb = (size_t)wrows * p.K * esz;
@@ -512,7 +517,7 @@ extern "C" int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int l
                              void* out, int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype,
                              int flags, const float* bias, float* stats_part, int* stats_rows_host, cy_stream_t s) {
     CY_ENTER();
-    if (flags & CY_CONV_AFFINE_ACT) return CY_ERR_ARG;
+    if (flags & (CY_CONV_AFFINE_ACT | CY_CONV_BNBWD_SUMS)) return CY_ERR_ARG;
     return conv_igemm_impl(g, N, GH, GW, GC, ldg, w, wrows, out, OH, OW, OC, ldo, ks, stride, pad, dtype, flags, bias,
                            stats_part, stats_rows_host, nullptr, nullptr, 0, nullptr, 0, s);
 }
@@ -525,4 +530,17 @@ extern "C" int cy_conv_bn_act_eval(const void* g, int N, int GH, int GW, int GC,
     if (flags & ~CY_CONV_TILE(15)) return CY_ERR_ARG;      // only the kernel / tile hint is accepted here
     return conv_igemm_impl(g, N, GH, GW, GC, ldg, w, wrows, out, OH, OW, OC, ldo, ks, stride, pad, dtype,
                            CY_CONV_AFFINE_ACT | flags, nullptr, nullptr, nullptr, scale, shift, act, res, ldres, s);
+}
+
+extern "C" int cy_conv_dgrad_bn_sums(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows,
+                                     void* out, int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype,
+                                     int flags, const void* raw, int ldraw, const float* mean, const float* invstd,
+                                     const float* scale, const float* shift, int act, float* sums_part, cy_stream_t s) {
+    CY_ENTER();
+    if (flags & ~(CY_CONV_TRANSPOSED | CY_CONV_ACCUM | CY_CONV_STATS_DET | CY_CONV_TILE(15))) return CY_ERR_ARG;
+    if (!raw || !mean || !invstd || !scale || !shift || !sums_part || ldraw % 8 || ((uintptr_t)raw & 15)) return CY_ERR_ARG;
+    if (dtype != CY_F16 && dtype != CY_BF16) return CY_ERR_ARG;
+    return conv_igemm_impl(g, N, GH, GW, GC, ldg, w, wrows, out, OH, OW, OC, ldo, ks, stride, pad, dtype,
+                           flags | CY_CONV_BNBWD_SUMS, nullptr, sums_part, nullptr, scale, shift, act, raw, ldraw, s, mean,
+                           invstd);
 }

@@ -300,6 +300,7 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
     __syncthreads();   // every wave is done with the ring: the epilogue reuses it
     if (is_loader) {   // the loaders hold no results; they only keep the block's barrier count whole
         if (p.flags & CY_CONV_STATS) { __syncthreads(); __syncthreads(); }
+        if (p.flags & CY_CONV_BNBWD_SUMS) __syncthreads();
         return;
     }
 
@@ -413,24 +414,100 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
                 }
         // (wave-private: the wave's own ds_writes are ordered before its ds_reads by lgkmcnt, no barrier needed)
         constexpr int RPI = 64 / CPR;            // pixel rows per store instruction
+        // CY_CONV_BNBWD_SUMS: this launch is the last writer of a BN layer's output gradient; its rows pass through here
+        // as whole 16-byte chunks, so the BN-backward sums of that layer (sum dz, sum dz * xhat with dz = g act'(z)) are
+        // taken on the way out -- one read of the layer's pre-BN tensor instead of a separate pass over (raw, g).
+        const bool bnsum = (p.flags & CY_CONV_BNBWD_SUMS) != 0;
+        const int cl8 = (lane % CPR) * 8;        // this lane's 8 channels inside the wave tile (the same for every row)
+        const bool cok = co_w + cl8 + 8 <= p.OC;
+        float bsc[8], bsh[8], s1[8], s2[8];      // s2 collects sum dz * raw; centred and scaled once at the end
+        if (bnsum) {
 #pragma unroll
-        for (int t = 0; t < WROWS / RPI; ++t) {
-            const int row = t * RPI + lane / CPR, c = lane % CPR;
-            const unsigned ob = orow[pw + row];
-            const int co = co_w + c * 8;
-            const tx8 v = *reinterpret_cast<const tx8*>(wt + row * ROWB + ((c ^ (row & (CPR - 1) & 7)) * 16));
-            if (ob == 0xFFFFFFFFu || co >= p.OC) continue;
-            T* dst = reinterpret_cast<T*>(p.o + ob) + co;
-            if (co + 8 <= p.OC) {
-                tx8 o = v;
-                if (accum) {
-                    const tx8 old = *reinterpret_cast<const tx8*>(dst);
+            for (int e = 0; e < 8; ++e) {
+                const int ch = min(co_w + cl8 + e, p.OC - 1);
+                bsc[e] = p.aff_scale[ch]; bsh[e] = p.aff_shift[ch];
+                s1[e] = 0.f; s2[e] = 0.f;
+            }
+        }
+        constexpr int NIT = WROWS / RPI, CHK = NIT <= 8 ? NIT : NIT / 2;
+        static_assert(NIT % CHK == 0, "row groups per prefetch chunk");
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (T)((float)v[e] + (float)old[e]);
+        for (int t0 = 0; t0 < NIT; t0 += CHK) {
+            // the pre-BN chunks (and, for a fan-in launch, the gradient already stored) of CHK row groups, requested back
+            // to back: one exposed memory latency per chunk instead of one per row group.  (The accumulators are in LDS by
+            // now, their registers are free.)
+            tx8 rawv[CHK], oldv[CHK];
+            unsigned obv[CHK];
+#pragma unroll
+            for (int t = 0; t < CHK; ++t) {
+                obv[t] = orow[pw + (t0 + t) * RPI + lane / CPR];
+                const bool ok = obv[t] != 0xFFFFFFFFu && cok;
+                if (bnsum) {
+                    const T* rp = reinterpret_cast<const T*>(p.res) + (size_t)((ok ? obv[t] : 0u) / ((unsigned)p.ldo * (unsigned)sizeof(T))) * p.ldres + co_w + cl8;
+                    rawv[t] = ok ? *reinterpret_cast<const tx8*>(rp) : tx8{};
                 }
-                *reinterpret_cast<tx8*>(dst) = o;
-            } else {
-                for (int e = 0; e < 8 && co + e < p.OC; ++e) dst[e] = (T)((float)v[e] + (accum ? (float)dst[e] : 0.f));
+                if (accum) oldv[t] = ok ? *reinterpret_cast<const tx8*>(reinterpret_cast<const T*>(p.o + obv[t]) + co_w + cl8) : tx8{};
+            }
+#pragma unroll
+            for (int t = 0; t < CHK; ++t) {
+                const int row = (t0 + t) * RPI + lane / CPR, c = lane % CPR;
+                const unsigned ob = obv[t];
+                const int co = co_w + c * 8;
+                const tx8 v = *reinterpret_cast<const tx8*>(wt + row * ROWB + ((c ^ (row & (CPR - 1) & 7)) * 16));
+                if (ob == 0xFFFFFFFFu || co >= p.OC) continue;
+                T* dst = reinterpret_cast<T*>(p.o + ob) + co;
+                if (cok) {
+                    tx8 o = v;
+                    if (accum) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (T)((float)v[e] + (float)oldv[t][e]);
+                    }
+                    *reinterpret_cast<tx8*>(dst) = o;
+                    if (bnsum) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)rawv[t][e];
+                            const float z = f * bsc[e] + bsh[e];
+                            const float dm = mish_grad<true>(z), dl = z > 0.f ? 1.f : 0.1f;
+                            const float dz = (float)o[e] * (p.act == CY_ACT_MISH ? dm : (p.act == CY_ACT_LEAKY ? dl : 1.f));
+                            s1[e] += dz;
+                            s2[e] += dz * f;
+                        }
+                    }
+                } else {
+                    for (int e = 0; e < 8 && co + e < p.OC; ++e) dst[e] = (T)((float)v[e] + (accum ? (float)dst[e] : 0.f));
+                }
+            }
+        }
+        if (bnsum) {
+            // fold the RPI rows a store instruction covers (lanes with equal lane % CPR), publish per (pixel-wave, channel),
+            // then one atomic per (channel, moment) of the block -- the table layout of the forward statistics
+            float* red = reinterpret_cast<float*>(smem + 8 * (WROWS * ROWB));      // [WM][2][BN], behind the waves' tiles
+            static_assert(8 * WROWS * ROWB + WM * 2 * BN * 4 <= NST * STAGE, "the sums fit behind the store tiles");
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int m = CPR; m < 64; m <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], m);
+                    s2[e] += __shfl_xor(s2[e], m);
+                }
+            }
+            if (lane < CPR) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = min(co_w + cl8 + e, p.OC - 1);
+                    red[(wm * 2 + 0) * BN + cw + cl8 + e] = s1[e];
+                    red[(wm * 2 + 1) * BN + cw + cl8 + e] = (s2[e] - p.bn_mean[ch] * s1[e]) * p.bn_invstd[ch];   // sum dz (raw - mean) invstd
+                }
+            }
+            __syncthreads();
+            float* srow = p.stats + (size_t)(p.stat_det ? tm : (lid & (CY_STAT_BINS - 1))) * 2 * p.OC;
+            for (int c = tid; c < 2 * BN; c += 512) {
+                const int mom = c / BN, cl = c - mom * BN, co = tn * BN + cl;
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) t += red[(2 * w + mom) * BN + cl];
+                if (co < p.OC) atomicAdd(srow + mom * p.OC + co, t);
             }
         }
     } else {
@@ -491,7 +568,9 @@ template <typename T>
 int pipe_dispatch(const IgemmParams& p, int cap, int bn, int variant, hipStream_t s) {
 #define CY_PIPE(BM_, BN_, WN_, NST_)                                                           \
     if (cap == BM_ && bn == BN_) {                                                             \
-        if (variant == 1 || (p.flags & CY_CONV_ACCUM)) return pipe_launch<T, BM_, BN_, WN_, NST_, false>(p, s); \
+        if (p.flags & CY_CONV_BNBWD_SUMS) {                                                                    \
+            if (variant == 1) return CY_ERR_ARG;   /* the sums live in the LDS-transposed store path */          \
+        } else if (variant == 1 || (p.flags & CY_CONV_ACCUM)) return pipe_launch<T, BM_, BN_, WN_, NST_, false>(p, s); \
         if (variant == 2) return pipe_launch<T, BM_, BN_, WN_, 2, true>(p, s);                                \
         if constexpr (NST_ == 3) { if (variant == 3) return pipe_launch<T, BM_, BN_, WN_, 3, true, 4>(p, s); } \
         return pipe_launch<T, BM_, BN_, WN_, NST_, true>(p, s);                                               \
@@ -555,7 +634,8 @@ int cy_pipe_try(const cyk::IgemmParams& p0, int dtype, hipStream_t s, int* used)
     }
     const int hint = (p0.flags >> CY_CONV_TILE_SHIFT) & 15;
     if (g_pipe_mode == 0 || hint == 1 || (dtype != CY_F16 && dtype != CY_BF16)) return 0;
-    if (g_pipe_mode == 1 && hint == 0 && !(p0.flags & CY_CONV_AFFINE_ACT)) return 0;
+    if (g_pipe_mode == 1 && hint == 0 && !(p0.flags & (CY_CONV_AFFINE_ACT | CY_CONV_BNBWD_SUMS))) return 0;
+    if ((p0.flags & CY_CONV_BNBWD_SUMS) && (p0.ldres % 8 || ((uintptr_t)p0.res & 15))) return 0;
     if (p0.GC % 64 || !p0.x_bias || (p0.flags & CY_CONV_BIAS_F32OUT) || p0.OC % 8 || p0.ldo % 8) return 0;
     if (((uintptr_t)p0.o & 15) || (p0.res && (p0.ldres % 4 || ((uintptr_t)p0.res & 7)))) return 0;
     if ((size_t)p0.N * p0.OH * p0.OW * p0.ldo * 2 >= 0xFFFFFF00ull) return 0;      // 32-bit output row offsets

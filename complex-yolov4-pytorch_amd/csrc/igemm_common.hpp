@@ -32,6 +32,10 @@ struct IgemmParams {
     const float* aff_shift;
     const unsigned char* res;
     int act, ldres;
+    // CY_CONV_BNBWD_SUMS epilogue (conv_pipe.hip): res / ldres = the producer layer's pre-BN tensor, aff_scale / aff_shift
+    // its BN affine, bn_mean / bn_invstd its batch statistics; the sums go to `stats`
+    const float* bn_mean;
+    const float* bn_invstd;
     unsigned x_bias;              // fast / pipelined kernels: bytes the gather descriptor's base sits below g (>= any negative row offset)
     int bm_eff;                   // conv_pipe.hip: pixels per tile actually used (<= the kernel's tile capacity)
     int stat_det;                 // statistics table: 0 = CY_STAT_BINS bins shared by the blocks (atomics, bin = tile % CY_STAT_BINS);

@@ -32,6 +32,12 @@ class Engine:
         # in a fixed order -- two runs of the same step are bit-identical.  Costs larger tables and slower folds.
         self.det = bool(deterministic)
         self._fwd_tile, self._dgrad_tile, self._fwd_tuned, self._dgrad_tuned = {}, {}, False, False
+        # BatchNorm-backward sums taken in the epilogue of the dgrad that last writes a layer's output gradient
+        # (ops.conv_dgrad_bn_sums) instead of a separate pass over (raw, gradient).  The plan marks where that is possible
+        # (graph.py::_mark_dgrad_bn_sums); the first backward times fused against separate per layer.  CY_DGRAD_BN_SUMS:
+        # 0 never, 1 (default) timed, 2 every marked layer untimed (what the CPU operator simulator's tests use).
+        self.dgrad_bn_sums = int(os.environ.get('CY_DGRAD_BN_SUMS', '1'))
+        self._dgrad_sums, self._sums_fused = {}, set()      # (P idx, run c0) -> (L record, tile hint);  {L idx}
         self.tdt = ops.torch_dtype(dt)
         self.act, self.gact = {}, {}
         f32 = dict(dtype=torch.float32, device=device)
@@ -393,16 +399,26 @@ class Engine:
         """Best kernel / tile hint for one conv launch shape: time every candidate (1 warm-up + 3 launches between HIP
         events) and keep the fastest.  The 4-wave and the 8-wave kernels are within +-10 % of each other on v4's layers and
         the winner depends on how tiles quantise over the 256 CUs, so it is measured, once per shape and process."""
-        best = _CONV_TUNE_MEMO.get(key)
-        if best is not None:
-            return best
-        hints = [1]
+        return self._time_hints_t(key, launch, cin, cout)[0]
+
+    def _time_hints_t(self, key, launch, cin, cout, pipe_only=False):
+        """-> (best hint, its time in ms for 3 launches); pipe_only leaves the 4-wave kernels out and returns (None, None)
+        when the pipelined kernel does not take the shape."""
+        memo = _CONV_TUNE_MEMO.get(key)
+        if memo is not None:
+            return memo
+        hints = [] if pipe_only else [1]
         if cin % 64 == 0 and cout % 8 == 0:
             hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h in (3, 8) and cout <= 64)]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        best, best_t = 1, None
+        best, best_t = (None if pipe_only else 1), None
         for h in hints:
-            launch(h)
+            try:
+                launch(h)
+            except ops.CyoloError:
+                if pipe_only:
+                    break
+                raise
             ev0.record()
             for _ in range(3):
                 launch(h)
@@ -411,8 +427,8 @@ class Engine:
             t = ev0.elapsed_time(ev1)
             if best_t is None or t < best_t * 0.98:      # a challenger must win by 2 %: ties keep the earlier candidate
                 best, best_t = h, t
-        _CONV_TUNE_MEMO[key] = best
-        return best
+        _CONV_TUNE_MEMO[key] = (best, best_t)
+        return best, best_t
 
     def _autotune_fwd(self):
         self._fwd_tuned = True
@@ -443,6 +459,15 @@ class Engine:
 
     def _autotune_dgrad(self):
         self._dgrad_tuned = True
+        can_fuse = self.fused_bn and self.training and self.dgrad_bn_sums and hasattr(ops, 'conv_dgrad_bn_sums')
+        if can_fuse and self.dgrad_bn_sums == 2:
+            sim = getattr(self.device, 'type', str(self.device)) != 'cuda'
+            for b in self.plan.bwd:
+                for ri, L in b.get('dx_sums', {}).items():
+                    if sim or (self.dt != CY_F32 and b['fwd']['cout'] % 64 == 0 and L['cout'] % 8 == 0):   # what the kernel takes
+                        self._dgrad_sums[(b['fwd']['idx'], b['dx'][ri][0].c0)] = (L, 6)
+                        self._sums_fused.add(L['idx'])
+            return
         if not self._tunable():
             return
         heads = {id(h['conv']): i for i, h in enumerate(self.plan.heads)}
@@ -452,15 +477,36 @@ class Engine:
             rec = b['fwd']
             dy = self.head_tmp[heads[id(rec)]] if id(rec) in heads else self.view(rec['out'], grad=True)
             wd, x = self.wd[rec['idx']], rec['x']
-            for ref, acc in b['dx']:
+            for ri, (ref, acc) in enumerate(b['dx']):
                 r0 = ref.c0 - x.c0
                 gv = self.view(ref, grad=True)
                 flags = CONV_TRANSPOSED | (CONV_ACCUM if acc else 0)
                 key = ('dgrad', self.dt, dy.N, dy.H, dy.W, dy.C, dy.ld, gv.H, gv.W, gv.C, gv.ld, rec['ks'], rec['stride'], acc)
                 # (timing an accumulating launch adds garbage into a gradient buffer that the real backward has not written
                 # yet at this point: every first writer of the step stores)
-                self._dgrad_tile[(rec['idx'], ref.c0)] = self._time_hints(key, lambda h: ops.conv_igemm(
+                hint, t_plain = self._time_hints_t(key, lambda h: ops.conv_igemm(
                     dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], flags=flags, tile=h), dy.C, ref.C)
+                self._dgrad_tile[(rec['idx'], ref.c0)] = hint
+                L = b.get('dx_sums', {}).get(ri) if can_fuse else None
+                if L is None:
+                    continue
+                # fused (dgrad + sums in its epilogue) against separate (best dgrad, then the reduce pass over raw and gradient)
+                vec, raw, act = self.bnvec[L['idx']], self.view(L['raw']), ops.ACT[L['act']]
+                tbl = self.bnpart_pair[0]
+                fhint, t_fused = self._time_hints_t(('dgrad+sums', act, raw.ld) + key[1:], lambda h: ops.conv_dgrad_bn_sums(
+                    dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], raw, vec[0], vec[1], vec[2], vec[3],
+                    act, tbl, flags=flags, tile=h), dy.C, ref.C, pipe_only=True)
+                if fhint is None:
+                    continue
+                rows = ops.bn_bwd_rows(raw.M, raw.C, self.dt, False)
+                _, t_reduce = self._time_hints_t(('bn_bwd_reduce', act, self.dt, raw.M, raw.C, raw.ld, gv.ld), lambda h: ops.bn_act_bwd_reduce(
+                    raw, gv, vec[0], vec[1], vec[2], vec[3], act, tbl, rows), 0, 0)
+                if t_fused < t_plain + t_reduce:
+                    self._dgrad_sums[(rec['idx'], ref.c0)] = (L, fhint)
+                    self._sums_fused.add(L['idx'])
+        if self.bnpart_pair is not None:     # the timed launches added into the sum tables
+            self.bnpart_pair[0].zero_()
+            self.bnpart_pair[1].zero_()
 
     def _wgrad(self, rec, dy, xv):
         """Weight gradient of one conv.  It is off the critical path of backward (only the optimizer needs it), so it
@@ -491,7 +537,17 @@ class Engine:
         for ref, acc in runs:
             r0 = ref.c0 - x.c0
             fl, by = self._conv_work(rec)
+            fused = self._dgrad_sums.get((rec['idx'], ref.c0))
             with ops.prof('igemm', fl * ref.C / x.C, by):
+                if fused is not None:
+                    # the sums of layer L go into the table L's backward will pick next (zeroed by the apply pass that just ran)
+                    L, hint = fused
+                    vec = self.bnvec[L['idx']]
+                    ops.conv_dgrad_bn_sums(dy, wd[r0:r0 + ref.C], ref.C, self.view(ref, grad=True), rec['ks'], rec['stride'],
+                                           rec['pad'], self.view(L['raw']), vec[0], vec[1], vec[2], vec[3], ops.ACT[L['act']],
+                                           self.bnpart_pair[self._bp], flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0),
+                                           tile=hint)
+                    continue
                 ops.conv_igemm(dy, wd[r0:r0 + ref.C], ref.C, self.view(ref, grad=True), rec['ks'], rec['stride'],
                                rec['pad'], flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0),
                                tile=self._dgrad_tile.get((rec['idx'], ref.c0), 0))
@@ -509,7 +565,10 @@ class Engine:
         if self.fused_bn:
             tbl, other = self.bnpart_pair[self._bp], self.bnpart_pair[self._bp ^ 1]
             self._bp ^= 1
-            ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, tbl, rows)
+            if idx in self._sums_fused:      # the dgrad that last wrote g already left the sums in tbl
+                rows = ops.conv_stats_rows(M, C, False)
+            else:
+                ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, tbl, rows)
         else:
             ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, self.bnpart, rows)
             ops.bn_bwd_finalize(self.bnpart, rows, C, self.dgs, self.dbs,

@@ -359,3 +359,42 @@ class Plan:
                 bwd.append(dict(op='add_bwd', fwd=rec, da=self._grad_runs(written, rec['a']),
                                 db=self._grad_runs(written, rec['b'])))
         self.bwd = bwd
+        self._mark_dgrad_bn_sums()
+
+    def _mark_dgrad_bn_sums(self):
+        """Which input-gradient launches may take the BatchNorm-backward sums of the layer that produced their output
+        tensor (cy_conv_dgrad_bn_sums): the stride-1 dgrad run of conv P that is the LAST writer of every channel of
+        dL/d(out of BN conv L), covers exactly that tensor, with P and L adjacent among the conv backward ops (the engine's
+        alternating sum tables rely on that).  Marks ``b_P['dx_sums'][run index] = L's record`` and
+        ``b_L['sums_from'] = P's index``; the engine decides per layer whether to use it."""
+        last = {}            # (storage id, channel) -> (bwd index, kind, run index) of the latest write
+        prev_conv = None     # bwd index of the latest conv_bwd / head_conv_bwd
+        for bi, b in enumerate(self.bwd):
+            op = b['op']
+            if op == 'conv_bwd':
+                L = b['fwd']
+                out = L['out']
+                writers = {last.get((out.st.sid, c)) for c in range(out.c0, out.c0 + out.C)}
+                b['sums_from'] = None
+                w = writers.pop() if len(writers) == 1 else None
+                if w is not None and w[1] == 'dgrad' and w[0] == prev_conv:
+                    pb = self.bwd[w[0]]
+                    ref, _ = pb['dx'][w[2]]
+                    if (ref.st is out.st and ref.c0 == out.c0 and ref.C == out.C and pb['fwd']['stride'] == 1
+                            and L['cout'] % 8 == 0):
+                        pb.setdefault('dx_sums', {})[w[2]] = L
+                        b['sums_from'] = pb['fwd']['idx']
+            if op in ('conv_bwd', 'head_conv_bwd'):
+                prev_conv = bi
+            writes = []
+            if op == 'conv_bwd':
+                writes += [(ref, 'res', ri) for ri, (ref, _) in enumerate(b['res_runs'])]
+            if op in ('conv_bwd', 'head_conv_bwd', 'pool_bwd', 'upsample_bwd', 'copy_bwd'):
+                writes += [(ref, 'dgrad' if op.endswith('conv_bwd') else op, ri) for ri, (ref, _) in enumerate(b['dx'])]
+            elif op == 'add_bwd':
+                writes += [(ref, op, ri) for ri, (ref, _) in enumerate(b['da'] + b['db'])]
+            elif op == 'zero_grad':
+                writes.append((b['ref'], op, 0))
+            for ref, kind, ri in writes:
+                for c in range(ref.c0, ref.c0 + ref.C):
+                    last[(ref.st.sid, c)] = (bi, kind, ri)

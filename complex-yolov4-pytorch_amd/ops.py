@@ -327,6 +327,15 @@ def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None
                stride, pad, g.dt, flags | (tile << CONV_TILE_SHIFT), _p(bias), _p(stats), None, _stream())
 
 
+def conv_dgrad_bn_sums(g, w, wrows, out, ks, stride, pad, raw, mean, invstd, scale, shift, act, sums, flags=0, tile=0):
+    """dgrad whose epilogue also adds the BN-backward sums of the layer that produced ``out``'s tensor into ``sums``
+    (cy_conv_dgrad_bn_sums; raises CyoloError where the pipelined kernel does not apply)."""
+    _require_gpu()
+    lib().call('cy_conv_dgrad_bn_sums', _p(g), g.N, g.H, g.W, g.C, g.ld, _p(w), wrows, _p(out), out.H, out.W, out.C, out.ld,
+               ks, stride, pad, g.dt, flags | (tile << CONV_TILE_SHIFT), _p(raw), raw.ld, _p(mean), _p(invstd), _p(scale),
+               _p(shift), act, _p(sums), _stream())
+
+
 def conv_bn_act_eval(g, w, wrows, out, ks, stride, pad, scale, shift, act, res=None, tile=0):
     """Eval-mode conv + BN affine + activation (+ shortcut) in one kernel."""
     _require_gpu()

@@ -29,7 +29,7 @@ enum { CY_ACT_LINEAR = 0, CY_ACT_LEAKY = 1, CY_ACT_MISH = 2 };
 enum { CY_ERR_ARG = -1 };
 /* cy_conv_igemm flags */
 enum { CY_CONV_STATS = 1, CY_CONV_BIAS_F32OUT = 2, CY_CONV_ACCUM = 4, CY_CONV_TRANSPOSED = 8, CY_CONV_AFFINE_ACT = 16,
-       CY_CONV_STATS_DET = 32 };
+       CY_CONV_STATS_DET = 32, CY_CONV_BNBWD_SUMS = 64 /* set by cy_conv_dgrad_bn_sums only */ };
 /* bits 8-11 of `flags`: kernel / tile hint of the call (0 = library default), see cy_conv_igemm */
 enum { CY_CONV_TILE_SHIFT = 8 };
 #define CY_CONV_TILE(h) ((h) << CY_CONV_TILE_SHIFT)
@@ -102,7 +102,7 @@ int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dt
  *   dgrad   : (CY_CONV_TRANSPOSED) out = dX, g = dY, w = wd:  gh = (oh+pad-kh)/stride when divisible
  * g: view (N,GH,GW,GC,ldg);  out: view (N,OH,OW,OC,ldo);  w: [wrows][ks*ks*GC].
  * flags: CY_CONV_STATS       -> also ADD (fp32 atomics) per-channel partial (sum, sumsq) of the f32 accumulators into
- *                               stats_part[bin][2][OC], bin = tile % 64  (BatchNorm batch statistics).  The table must
+ *                               stats_part[bin][2][OC], bin = tile % 16  (BatchNorm batch statistics).  The table must
  *                               be zero on entry; cy_bn_finalize folds it and leaves it zeroed.
  *        CY_CONV_BIAS_F32OUT -> out is float regardless of dtype and bias[OC] is added (the YOLO head convs)
  *        CY_CONV_ACCUM       -> out += result (gradient fan-in of routes / shortcuts)
@@ -121,6 +121,22 @@ int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const v
 int cy_conv_bn_act_eval(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out,
                         int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, const float* scale,
                         const float* shift, int act, const void* res, int ldres, int flags, cy_stream_t s);
+
+/* Input-gradient conv (dgrad) whose epilogue ALSO accumulates the BatchNorm-backward sums of the layer that produced
+ * its output tensor: with out = dL/dy of that layer (after the CY_CONV_ACCUM fan-in, as stored), raw = the layer's
+ * pre-BN tensor (same pixels, row stride ldraw), z = raw*scale + shift,
+ *     sums_part[bin][0][c] += sum_p out * act'(z)            (= d beta)
+ *     sums_part[bin][1][c] += sum_p out * act'(z) * (raw - mean) * invstd      (= d gamma)
+ * -- the table cy_bn_act_bwd_reduce would produce from a second pass over (raw, out); cy_bn_act_bwd_apply_fused takes it
+ * with rows = cy_conv_stats_rows().  The layer's gradient tensor is then read once (by the apply pass) instead of twice.
+ * Reference: the autograd graph of Conv2d -> BatchNorm2d -> Mish, darknet2pytorch.py:247-278.
+ * Runs on the 8-wave pipelined kernel only: 16-bit dtype, stride 1, GC % 64 == 0, OC % 8 == 0, ldo % 8 == 0,
+ * ldraw % 8 == 0, 16-byte aligned raw; anything else returns CY_ERR_ARG (the caller keeps the separate reduce pass).
+ * flags: CY_CONV_TRANSPOSED, CY_CONV_ACCUM, CY_CONV_STATS_DET (one table row per pixel tile), CY_CONV_TILE(2..9). */
+int cy_conv_dgrad_bn_sums(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out,
+                          int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags,
+                          const void* raw, int ldraw, const float* mean, const float* invstd, const float* scale,
+                          const float* shift, int act, float* sums_part, cy_stream_t s);
 
 /* Number of kernel launches since load that ran on the 8-wave pipelined kernel (csrc/conv_pipe.hip: CY_F16 / CY_BF16,
  * Cin a multiple of 64, 16-bit output with OC and ldo multiples of 8, enough pixel tiles to fill the chip); every

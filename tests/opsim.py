@@ -77,6 +77,18 @@ def wgrad_reduce_multi(desc, blocks, scale, accumulate):
         wgrad_reduce(part, split, corows, cip, ks, Co, Ci, scale, accumulate, grad)
 
 
+def conv_dgrad_bn_sums(g, w, wrows, out, ks, stride, pad, raw, mean, invstd, scale, shift, act, sums, flags=0, tile=0):
+    conv_igemm(g, w, wrows, out, ks, stride, pad, flags=flags)
+    C = out.C
+    dz = _dz(raw, out, scale, shift, act)
+    xh = (_nchw(raw) - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+    rows = real.conv_stats_rows(out.M, C)
+    p = sums.view(-1)[:rows * 2 * C].view(rows, 2, C)
+    assert float(p.abs().max()) == 0.0, 'the sums table must be zero on entry'
+    p[0, 0] = dz.sum((0, 2, 3))
+    p[0, 1] = (dz * xh).sum((0, 2, 3))
+
+
 def conv_igemm(g, w, wrows, out, ks, stride, pad, flags=0, bias=None, stats=None, tile=0):
     x = _nchw(g)
     kk = ks * ks
@@ -299,7 +311,7 @@ def yolo_loss(logits, B, G, A, C, targets, anchors, img_size, ignore_thresh, use
 
 
 NAMES = ['check_device_tensor', 'nchw_to_nhwc', 'pack_weights_into', 'make_pack_table', 'pack_weights_multi',
-         'make_reduce_table', 'wgrad_reduce_multi', 'conv_bn_act_eval', 'conv_igemm', 'conv_wgrad', 'wgrad_reduce',
+         'make_reduce_table', 'wgrad_reduce_multi', 'conv_bn_act_eval', 'conv_igemm', 'conv_dgrad_bn_sums', 'conv_wgrad', 'wgrad_reduce',
          'bn_finalize', 'bn_eval_affine', 'bn_act_fwd', 'bn_act_fwd_fused', 'bn_act_bwd_apply_fused', 'bn_act_bwd_reduce', 'bn_bwd_finalize', 'bn_act_bwd_apply',
          'maxpool_argmax_bytes', 'maxpool_fwd', 'maxpool_bwd', 'upsample_fwd', 'upsample_bwd', 'slice_copy', 'slice_add', 'f32_to_view',
          'zero_view', 'bias_grad', 'yolo_decode', 'yolo_loss']

@@ -307,3 +307,93 @@ def test_fused_bn_finalisers_match_the_two_kernel_path(dt, C, M, act):
     torch.testing.assert_close(gb2, gb1, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(dx2.buf.float(), dx1.buf.float(), **tol)
     assert torch.equal(rg2.buf, rg1.buf)
+
+
+# (Cin of the conv = channels of the incoming gradient dy, Cout = channels of the produced gradient, ks, H, N)
+DGRAD_SUMS = [(64, 128, 3, 38, 4), (128, 64, 1, 76, 2), (256, 256, 3, 19, 16), (512, 1024, 1, 19, 3), (64, 64, 3, 152, 1)]
+
+
+@pytest.mark.parametrize('dt', [CY_F16, CY_BF16])
+@pytest.mark.parametrize('accum', [False, True])
+@pytest.mark.parametrize('act', ['mish', 'leaky', 'linear'])
+@pytest.mark.parametrize('case', DGRAD_SUMS)
+def test_dgrad_bn_sums_epilogue_matches_separate_reduce(dt, accum, act, case):
+    """cy_conv_dgrad_bn_sums = cy_conv_igemm (dgrad, with / without fan-in accumulation) followed by cy_bn_act_bwd_reduce
+    over (raw, stored gradient): same gradient tensor bit for bit, same (d beta, d gamma) sums up to fp32 summation order."""
+    Cdy, Cg, ks, H, N = case
+    pad = (ks - 1) // 2
+    g = torch.Generator().manual_seed(Cdy * 3 + Cg + H)
+    tdt = ops.torch_dtype(dt)
+    dy = View.alloc(N, H, H, Cdy, dt); dy.buf.copy_(torch.randn(dy.buf.numel(), generator=g).to(tdt))
+    raw = View.alloc(N, H, H, Cg, dt); raw.buf.copy_(torch.randn(raw.buf.numel(), generator=g).to(tdt))
+    w = torch.randn(Cdy, Cg, ks, ks, generator=g).to(DEV) * (1.0 / (ks * ks * Cdy) ** 0.5)
+    _, wd = ops.pack_weights(w, Cdy, Cg, dt)
+    vec = torch.stack([torch.randn(Cg, generator=g) * 0.1, torch.rand(Cg, generator=g) + 0.5,
+                       torch.rand(Cg, generator=g) + 0.5, torch.randn(Cg, generator=g) * 0.2]).to(DEV)
+    a = ops.ACT[act]
+    base = torch.randn(raw.buf.numel(), generator=g).to(DEV).to(tdt)
+    flags = ops.CONV_TRANSPOSED | (ops.CONV_ACCUM if accum else 0)
+    M = N * H * H
+    rows = ops.conv_stats_rows(M, Cg)
+    ref_sums = None
+    for hint in (2, 3, 4, 5, 6, 7, 8, 9):
+        if hint in (3, 8) and Cg <= 64:
+            continue
+        # separate: the same kernel / tile without the sums, then the reduce pass
+        g1 = View.alloc(N, H, H, Cg, dt); g1.buf.copy_(base)
+        ops.conv_igemm(dy, wd, Cg, g1, ks, 1, pad, flags=flags, tile=hint)
+        if ref_sums is None:
+            part = torch.zeros(ops.bn_bwd_rows(M, Cg, dt), 2, Cg, device=DEV)
+            ops.bn_act_bwd_reduce(raw, g1, vec[0], vec[1], vec[2], vec[3], a, part)
+            ref_sums = part.double().sum(0)
+        g2 = View.alloc(N, H, H, Cg, dt); g2.buf.copy_(base)
+        tbl = torch.zeros(rows, 2, Cg, device=DEV)
+        ops.conv_dgrad_bn_sums(dy, wd, Cg, g2, ks, 1, pad, raw, vec[0], vec[1], vec[2], vec[3], a, tbl, flags=flags, tile=hint)
+        if not accum:
+            assert torch.equal(g2.buf, g1.buf), hint     # (accumulating launches take the direct-store epilogue without the sums)
+        else:
+            tol = 2e-2 if dt == CY_BF16 else 3e-3
+            torch.testing.assert_close(g2.buf.float(), g1.buf.float(), rtol=tol, atol=tol)
+            part = torch.zeros(ops.bn_bwd_rows(M, Cg, dt), 2, Cg, device=DEV)
+            ops.bn_act_bwd_reduce(raw, g2, vec[0], vec[1], vec[2], vec[3], a, part)
+            ref_sums = part.double().sum(0)
+        got = tbl.double().sum(0)
+        scale = ref_sums.abs().max(1, keepdim=True).values + 1e-6
+        assert float(((got - ref_sums).abs() / scale).max()) < 2e-5, (hint, float(((got - ref_sums).abs() / scale).max()))
+
+
+def test_dgrad_bn_sums_rejects_what_the_pipelined_kernel_cannot_run():
+    dy, raw, gv = View.alloc(1, 8, 8, 32, CY_F16), View.alloc(1, 8, 8, 64, CY_F16), View.alloc(1, 8, 8, 64, CY_F16)
+    wd = torch.zeros(64, 32, dtype=torch.float16, device=DEV)
+    v = torch.ones(64, device=DEV)
+    tbl = torch.zeros(16 * 2 * 64, device=DEV)
+    with pytest.raises(ops.CyoloError):      # 32 gradient channels: not a multiple of 64
+        ops.conv_dgrad_bn_sums(dy, wd, 64, gv, 1, 1, 0, raw, v, v, v, v, ops.ACT['mish'], tbl, flags=ops.CONV_TRANSPOSED)
+    dy32 = View.alloc(1, 8, 8, 64, CY_F32)
+    with pytest.raises(ops.CyoloError):      # fp32 parity mode keeps the separate pass
+        ops.conv_dgrad_bn_sums(dy32, wd, 64, View.alloc(1, 8, 8, 64, CY_F32), 1, 1, 0, View.alloc(1, 8, 8, 64, CY_F32), v, v, v, v,
+                               ops.ACT['mish'], tbl, flags=ops.CONV_TRANSPOSED)
+
+
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+def test_model_backward_with_dgrad_sums_matches_separate_reduce(monkeypatch, dtype):
+    """complex_yolov4.cfg train step with every marked layer taking its BN-backward sums from the dgrad epilogue
+    (CY_DGRAD_BN_SUMS=2) against the same step with the separate reduce pass (=0): same loss, parameter gradients equal up
+    to the run-to-run noise band of the default (atomics) mode."""
+    x, tg = syn.bev_images(4, 416, seed=3), syn.targets(4, 6, 416, seed=3)
+    grads = {}
+    for mode in ('0', '2', '0'):
+        monkeypatch.setenv('CY_DGRAD_BN_SUMS', mode)
+        m = _model('complex_yolov4.cfg', dtype)
+        m.train()
+        loss, _ = m(x.to(DEV), tg.to(DEV))
+        loss.sum().backward()
+        eng = next(iter(m._engines.values()))
+        assert (len(eng._sums_fused) >= 70) if mode == '2' else not eng._sums_fused
+        grads.setdefault(mode, []).append(torch.cat([p.grad.reshape(-1).float() for p in m.parameters()]).cpu())
+        assert bool(torch.isfinite(grads[mode][-1]).all())
+    a0, a1 = grads['0']
+    b = grads['2'][0]
+    noise = float((a0 - a1).norm() / a0.norm())
+    diff = float((b - a0).norm() / a0.norm())
+    assert diff < max(3 * noise, 2e-2), (diff, noise)

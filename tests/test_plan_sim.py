@@ -33,6 +33,10 @@ def test_plan_structure_v4():
     assert len(plan.fused_into) == 23                                            # every [shortcut] is folded
     assert not any(r['op'] in ('copy', 'add') for r in plan.fwd)                 # every route is a view
     assert plan.shapes[113] == (2048, 19, 19) and plan.shapes[0] == (32, 608, 608)
+    # BN layers whose backward sums can ride on the dgrad that last writes their gradient (residual-block convs, CSP
+    # splits, the conv before each head); not: members of a concatenation, inputs of stride-2 convs
+    marked = sum(len(b.get('dx_sums', {})) for b in plan.bwd)
+    assert marked == sum(b.get('sums_from') is not None for b in plan.bwd) and 60 <= marked <= 107, marked
     # no backward op needs a mixed-state fan-in on these cfgs
     for b in plan.bwd:
         for key in ('dx', 'res_runs'):
@@ -92,12 +96,15 @@ def test_darknet_sim_matches_reference_golden(monkeypatch, golden, tag, cfg, B, 
         np.testing.assert_allclose(o[:, ::97].numpy(), g['%s_eval_rows' % tag], rtol=2e-2, atol=2e-3)
 
 
-def test_mini_cfg_all_block_types_tight_gradients(monkeypatch):
+@pytest.mark.parametrize('dgrad_sums', [0, 2])
+def test_mini_cfg_all_block_types_tight_gradients(monkeypatch, dgrad_sums):
     """All-Mish mini cfg (grouped route, copied cat member, alias route, fused shortcut, SPP, upsample, two heads):
-    smooth activations, so EVERY parameter gradient must agree with the oracle tightly."""
+    smooth activations, so EVERY parameter gradient must agree with the oracle tightly.  dgrad_sums = 2: every layer the
+    plan marks takes its BatchNorm-backward sums from the epilogue of the dgrad that last writes its gradient."""
     from oracle import darknet_ref
     from tests.util import grad_rel_errors, mini_cfg_path
     opsim.install(monkeypatch)
+    monkeypatch.setenv('CY_DGRAD_BN_SUMS', str(dgrad_sums))
     cfg = mini_cfg_path()
     torch.manual_seed(0)
     model = Darknet(cfg, use_giou_loss=True, dtype='f32')
@@ -119,6 +126,9 @@ def test_mini_cfg_all_block_types_tight_gradients(monkeypatch):
     np.testing.assert_allclose(out.numpy(), o_ref.detach().numpy(), rtol=1e-3, atol=1e-3)
     errs = grad_rel_errors([(n, p.grad) for n, p in model.named_parameters()], {k: v.grad for k, v in params.items()})
     assert max(errs.values()) < 2e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    eng = model._engine_for(torch.zeros(2, 3, 64, 64))
+    marked = sum(len(b.get('dx_sums', {})) for b in eng.plan.bwd)
+    assert marked >= 3 and len(eng._sums_fused) == (marked if dgrad_sums else 0)
 
 
 def test_gradient_accumulation_and_zero_grad(monkeypatch):
