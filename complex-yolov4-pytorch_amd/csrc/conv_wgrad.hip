@@ -521,33 +521,40 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 template <int KK>
 __device__ __forceinline__ void fold_pairs(const cy_reduce_desc& d, long first_pair, float scale, int accumulate,
                                            float* lds) {
+    // d.lanes threads share a pair and split the slabs between them (small layers with a large split-K factor have
+    // few pairs and a long serial chain per thread otherwise: 128 slabs x 9 taps was 0.3 ms for ONE block, exposed at
+    // the end of backward); the partial sums meet in LDS in a fixed order
+    const int lanes = d.lanes, PB = 256 / lanes;
+    const int pl = threadIdx.x % PB, sl = threadIdx.x / PB;
     const long npairs = (long)d.Co * d.Ci;
     const int ncols = KK * d.CiPad;
     const size_t slab = (size_t)d.CoRows * ncols;
-    const long p = first_pair + threadIdx.x;
+    const long p = first_pair + pl;
     float acc[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[t] = 0.f;
     if (p < npairs) {
         const int ci = (int)(p % d.Ci), co = (int)(p / d.Ci);
         const float* src = d.part + (size_t)co * ncols + ci;
-        for (int sp = 0; sp < d.split; ++sp) {
+        for (int sp = sl; sp < d.split; sp += lanes) {
 #pragma unroll
             for (int t = 0; t < KK; ++t) acc[t] += src[(size_t)sp * slab + t * d.CiPad];
         }
     }
-    if (KK == 1) {
+    if (KK == 1 && lanes == 1) {
         if (p < npairs) d.grad[p] = scale * acc[0] + (accumulate ? d.grad[p] : 0.f);
         return;
     }
 #pragma unroll
-    for (int t = 0; t < KK; ++t) lds[threadIdx.x * KK + t] = acc[t];
+    for (int t = 0; t < KK; ++t) lds[threadIdx.x * KK + t] = acc[t];     // [sl][pl][t]
     __syncthreads();
     const long total = npairs * KK, o0 = first_pair * KK;
-#pragma unroll
-    for (int i = 0; i < KK; ++i) {
-        const int o = i * 256 + threadIdx.x;
-        if (o0 + o < total) d.grad[o0 + o] = scale * lds[o] + (accumulate ? d.grad[o0 + o] : 0.f);
+    const int span = PB * KK;                       // this block's contiguous run of the OIHW gradient
+    for (int o = threadIdx.x; o < span; o += 256) {
+        if (o0 + o >= total) break;
+        float v = lds[o];
+        for (int l = 1; l < lanes; ++l) v += lds[l * span + o];
+        d.grad[o0 + o] = scale * v + (accumulate ? d.grad[o0 + o] : 0.f);
     }
 }
 
@@ -556,7 +563,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const cy_reduce
                                                                 int accumulate) {
     __shared__ float lds[256 * 9];
     const cy_reduce_desc d = desc[blocks[2 * blockIdx.x]];
-    const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
+    const long first = (long)blocks[2 * blockIdx.x + 1] * 32;
     if (d.ks == 1) fold_pairs<1>(d, first, scale, accumulate, lds);
     else if (d.ks == 3) fold_pairs<9>(d, first, scale, accumulate, lds);
     else {   // other kernel sizes: one pair per thread, strided writes
@@ -643,7 +650,7 @@ extern "C" int cy_wgrad_reduce(const float* part, int split, int CoRows, int CiP
 extern "C" int cy_wgrad_reduce_multi(const cy_reduce_desc* desc, const int32_t* blocks, int nblocks, float scale,
                                      int accumulate, cy_stream_t s) {
     CY_ENTER();
-    if (!desc || !blocks || nblocks < 1) return CY_ERR_ARG;
+    if (!desc || !blocks || nblocks < 1) return CY_ERR_ARG;   // (desc[i].lanes in {1, 2, 4, 8}: the table builder's contract)
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, scale, accumulate);
     CY_LAUNCH_CHECK();
     return 0;

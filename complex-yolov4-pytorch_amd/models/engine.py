@@ -184,18 +184,27 @@ class Engine:
         ops.pack_weights_multi(self._pack_table[0], self._pack_table[1], self.dt)
 
     def _build_reduce_groups(self):
-        """Partition the convs (backward order) into groups of >= 16M gradient elements; one fold launch per group."""
+        """Partition the convs (backward order) into fold groups, one launch per group.  A fold costs its slab bytes, and
+        the LAST one runs after the main stream has nothing left to hide it behind (rocprofv3 timeline, round 2: a last
+        group cut by gradient count held 0.68 ms of slabs, exposed before the optimizer) -- so the groups are cut by slab
+        bytes (a quarter of the total each) and the final group only holds the last layers, <= 8 MB of slabs."""
+        recs = [b['fwd'] for b in self.plan.bwd if b['op'] in ('conv_bwd', 'head_conv_bwd')]
+        nbytes = [4 * self.wsplit[r['idx']] * _pad32(r['cout']) * r['ks'] * r['ks'] * r['cin_pad'] for r in recs]
+        tail, acc = len(recs) - 1, nbytes[-1] if recs else 0
+        while tail > 0 and acc + nbytes[tail - 1] <= (8 << 20):
+            tail -= 1
+            acc += nbytes[tail]
+        target = max(1, sum(nbytes[:tail]) // 4)
         groups, cur, n = [], [], 0
-        for b in self.plan.bwd:
-            if b['op'] not in ('conv_bwd', 'head_conv_bwd'):
-                continue
-            rec = b['fwd']
+        for i, rec in enumerate(recs[:tail]):
             cur.append(rec)
-            n += rec['cout'] * rec['cin'] * rec['ks'] * rec['ks']
-            if n >= (16 << 20):
+            n += nbytes[i]
+            if n >= target:
                 groups.append(cur); cur, n = [], 0
         if cur:
             groups.append(cur)
+        if recs[tail:]:
+            groups.append(recs[tail:])
         self._reduce_groups = []
         for g in groups:
             items = []

@@ -248,12 +248,19 @@ def pack_weights_multi(desc, blocks, dt):
 def make_reduce_table(items, device):
     """items: [(part tensor, grad tensor, split, CoRows, CiPad, ks, Co, Ci)]."""
     import struct
-    raw, counts = b'', []
-    for part, grad, split, corows, cip, ks, Co, Ci in items:
-        raw += struct.pack('<QQiiiiii', part.data_ptr(), grad.data_ptr(), split, corows, cip, ks, Co, Ci)
-        counts.append(Co * Ci)             # the fold's unit is one (co, ci) pair with all its taps; 256 pairs per block
+    raw, rows = b'', []
+    for i, (part, grad, split, corows, cip, ks, Co, Ci) in enumerate(items):
+        # the fold's unit is one (co, ci) pair with all its taps.  Layers with few pairs and many slabs (the first
+        # stages: split-K up to 128) let 2-8 threads share a pair, each folding every lanes-th slab
+        lanes = 1
+        if ks in (1, 3) and Co * Ci < 65536:
+            while lanes < 8 and split >= 16 * lanes:
+                lanes *= 2
+        raw += struct.pack('<QQiiiiiiii', part.data_ptr(), grad.data_ptr(), split, corows, cip, ks, Co, Ci, lanes, 0)
+        pb = 256 // lanes if ks in (1, 3) else 256
+        rows += [(i, first // 32) for first in range(0, Co * Ci, pb)]
     desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-    blocks = torch.tensor(_block_table(counts, 256), dtype=torch.int32, device=device)
+    blocks = torch.tensor(rows, dtype=torch.int32, device=device)
     return desc, blocks
 
 

@@ -55,7 +55,7 @@ int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad, int CiPad
  * (descriptor index, first element / 256) pairs, one per 256-thread block covering CY_MULTI_ELEMS elements; for the
  * pack table an "element" run of CY_MULTI_ELEMS stands for one 64 x 64 (co, ci) tile of the padded weight matrix
  * (tile = second entry / 4, tiles enumerated ci-fastest, ks <= 3); for the reduce table the unit is one (co, ci) pair
- * with all ks*ks taps and a block covers 256 pairs (second entry = first pair / 256). */
+ * with all ks*ks taps and a block covers 256 / lanes pairs (second entry = first pair / 32). */
 typedef struct {
     const float* w; void* wf; void* wd;
     int Co, Ci, ks, CoPad, CiPad, pad_;
@@ -63,6 +63,7 @@ typedef struct {
 typedef struct {
     const float* part; float* grad;
     int split, CoRows, CiPad, ks, Co, Ci;
+    int lanes, pad_;     /* threads sharing one (co, ci) pair, each folding every lanes-th slab: 1, 2, 4 or 8 (ks 1 / 3) */
 } cy_reduce_desc;
 enum { CY_MULTI_ELEMS = 1024 };
 int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* blocks, int nblocks, int dtype, cy_stream_t s);

@@ -20,9 +20,9 @@ CFG = os.path.join(os.path.dirname(__file__), '..', 'complex-yolov4-pytorch_amd'
 DEV = 'cuda'
 
 
-def _model(cfg, giou, dtype):
+def _model(cfg, giou, dtype, **kw):
     torch.manual_seed(0)
-    m = Darknet(os.path.join(CFG, cfg), use_giou_loss=giou, dtype=dtype)
+    m = Darknet(os.path.join(CFG, cfg), use_giou_loss=giou, dtype=dtype, **kw)
     sd = m.state_dict()
     sd.update({k: syn.fill_tensor(k, tuple(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point})
     m.load_state_dict(sd)
@@ -36,7 +36,10 @@ CASES = [('tiny', 'complex_yolov4_tiny.cfg', 2, 608), ('v4', 'complex_yolov4.cfg
 @pytest.mark.parametrize('mode', ['giou', 'mse'])
 def test_train_step_f32_parity(golden, tag, cfg, B, S, mode):
     g = golden('darknet')
-    model = _model(cfg, mode == 'giou', 'f32')
+    # v4 at 416 / batch 1 is ill-conditioned enough (BN over 169 samples at stride 32) that the summation-order noise of
+    # the default mode's fp32 atomics occasionally (about 1 run in 10) pushes one gradient norm past the band below: the
+    # parity check of that case runs in the deterministic mode (fixed-order folds, bit-identical from run to run)
+    model = _model(cfg, mode == 'giou', 'f32', deterministic=(tag == 'v4'))
     model.train()
     x, tg = syn.bev_images(B, S, seed=1).to(DEV), syn.targets(B, 6, S, seed=1).to(DEV)
     loss, out = model(x, tg)

@@ -381,7 +381,7 @@ def test_table_driven_pack_and_reduce_match_single_calls():
             torch.testing.assert_close(wd, rd, rtol=0, atol=0)
     ritems, refs = [], []
     for i, (Co, Ci, ks, cip) in enumerate(shapes):
-        cop, split = (Co + 31) // 32 * 32, 3 + i
+        cop, split = (Co + 31) // 32 * 32, (3, 40, 5, 130)[i]      # 40 / 130 slabs: 2 and 8 threads share a (co, ci) pair
         part = _rand(split, cop, ks * ks * cip, seed=60 + i).to(DEV)
         grad = torch.ones(Co, Ci, ks, ks, device=DEV)
         ref = torch.ones(Co, Ci, ks, ks, device=DEV)
@@ -391,7 +391,7 @@ def test_table_driven_pack_and_reduce_match_single_calls():
     desc, blocks = ops.make_reduce_table(ritems, DEV)
     ops.wgrad_reduce_multi(desc, blocks, 0.25, True)
     for it, ref in zip(ritems, refs):
-        torch.testing.assert_close(it[1], ref, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(it[1], ref, rtol=1e-5, atol=1e-5)
 
 
 def test_fused_adam_matches_torch_adam():
