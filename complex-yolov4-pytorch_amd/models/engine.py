@@ -99,6 +99,7 @@ class Engine:
         # split-K slabs of every conv stay resident until their group is folded (table-driven, a few launches per step)
         self.wpart = torch.empty(max(max_wpart, 1), **f32)
         self._pack_table = self._pack_key = self._pack_epoch = None
+        self._in_side_head = self._heads_on_side = False
         self.fwd_serial = 0
         self._reduce_groups = None
         use_side = training and getattr(device, 'type', str(device)) == 'cuda' and os.environ.get('CY_WGRAD_SIDE_STREAM', '1') != '0'
@@ -161,6 +162,9 @@ class Engine:
                 self._autotune_fwd()
             for rec in plan.fwd:
                 getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
+        if self._heads_on_side:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self._heads_on_side = False
         return self.outputs
 
     def _pack_all(self, weights_epoch=None):
@@ -296,6 +300,21 @@ class Engine:
         ops.slice_add(self.view(rec['a']), self.view(rec['b']), self.view(rec['out']))
 
     def _f_yolo(self, rec, targets, use_giou, img_size):
+        if self.side is not None and targets is not None and not self._in_side_head and os.environ.get('CY_HEADS_SIDE', '1') != '0':
+            # training: the decode + loss kernels of a head are a dozen two-wave launches (one lane per target in the
+            # polygon clip), ~0.15 ms of latency that nothing downstream needs before the loss is read -- they run on the
+            # side stream beside the trunk convs that follow the head (forward() joins the streams at the end)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ev)
+            self._in_side_head = True
+            try:
+                with torch.cuda.stream(self.side), ops.stream_scope(self.side):
+                    self._f_yolo(rec, targets, use_giou, img_size)
+            finally:
+                self._in_side_head = False
+            self._heads_on_side = True
+            return
         h = rec['head']
         logits = self.act[rec['logits'].st.sid]
         ops.yolo_decode(logits, self.N, rec['G'], rec['A'], rec['C'], rec['anchors'], img_size, self.outputs,
