@@ -199,6 +199,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the configuration\'s)')
     ap.add_argument('--size', type=int, default=None)
     ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16', 'f32'])
+    ap.add_argument('--deterministic', action='store_true', help='bit-reproducible reductions (Darknet(..., deterministic=True))')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the brief measurement of the other configurations')
@@ -241,7 +242,7 @@ def main():
         return
 
     torch.manual_seed(0)
-    model = Darknet(CFG, use_giou_loss=True, dtype=a.dtype).to(dev)
+    model = Darknet(CFG, use_giou_loss=True, dtype=a.dtype, deterministic=a.deterministic).to(dev)
     model.train()
     net = RcclDataParallel(model) if (world > 1 or force_ddp) else model
     opt = create_optimizer(_OptCfg, model)          # FusedAdam (cy_adam_multi) on the device
@@ -295,7 +296,7 @@ def main():
             ridge = MFMA_PEAK_TFLOPS[a.dtype] * 1e12 / HBM_PEAK_BPS
             acc = {'mfma': [0.0, 0.0, 0.0, 0], 'hbm': [0.0, 0.0, 0.0, 0]}
             for kind, fl, nb, ev0, ev1 in ops.PROFILER.records:
-                if kind != 'igemm' or nb <= 0:
+                if kind not in ('igemm', 'igemm_sums') or nb <= 0:
                     continue
                 k = 'mfma' if fl / nb >= ridge else 'hbm'
                 t = max(ev0.elapsed_time(ev1), 1e-6)
@@ -312,13 +313,17 @@ def main():
             e.side = sd
         sync()
     if rank == 0 and not a.no_roofline:
-        ig = summ.get('igemm')
+        plain, fused = summ.get('igemm'), summ.get('igemm_sums')
+        # the conv family = every forward / dgrad launch as it runs in the step; the dgrad launches that also take the
+        # BatchNorm-backward sums of the producer layer in their epilogue (cy_conv_dgrad_bn_sums) are bracketed apart so
+        # that the cost of that epilogue is visible (`epilogue_split`)
+        ig = {k: plain[k] + (fused[k] if fused else 0) for k in ('flops', 'bytes', 'ms', 'ms_raw', 'launches')} if plain else None
         if ig:
             ach = ig['flops'] / (ig['ms_raw'] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[a.dtype]
             tr = pmc_traffic('igemm', a)
             roofline = dict(bound='mfma', kernel='implicit-GEMM conv kernels (forward + dgrad launches: igemm_fast_kernel / igemm_kernel '
-                                                 '4-wave tiles and igemm_pipe_kernel 8-wave tiles, chosen per layer)',
+                                                 '4-wave tiles and igemm_pipe_kernel 8-wave tiles, chosen per layer; dgrad launches that also accumulate BatchNorm-backward sums included)',
                             achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
                             traffic=(tr or {}).get('bytes_per_launch'), traffic_detail=tr,
                             launches_per_step=ig['launches'] // 2, avg_launch_us=round(1e3 * ig['ms_raw'] / ig['launches'], 2),
@@ -334,6 +339,10 @@ def main():
                                                 launches_per_step=wg['launches'] // 2,
                                                 avg_launch_us=round(1e3 * wg['ms_raw'] / wg['launches'], 2))
             roofline['conv_ms_per_step'] = round((ig['ms_raw'] + (wg['ms_raw'] if wg else 0)) / 2, 3)
+            roofline['epilogue_split'] = {
+                name: dict(launches_per_step=f['launches'] // 2, avg_launch_us=round(1e3 * f['ms_raw'] / f['launches'], 2),
+                           achieved=round(f['flops'] / (f['ms_raw'] * 1e-3) / 1e12, 2), unit='TFLOP/s')
+                for name, f in (('conv_only', plain), ('dgrad_with_bn_backward_sums', fused)) if f}
             roofline['by_bound'] = by_bound   # launches above the ridge point against the MFMA peak, the rest against HBM
     if world > 1:
         dist.barrier()
@@ -360,7 +369,9 @@ def main():
             'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': 'complex_yolov4.cfg train step (fwd + rotated-GIoU loss + bwd + Adam), batch %d per GPU, %dx%dx3 synthetic BEV, 6 targets/image'
                                    % (a.batch, a.size, a.size),
-                       'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4)},
+                       'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4),
+                       'deterministic': bool(a.deterministic),
+                       'dgrad_bn_sums_layers': max((len(e._sums_fused) for e in model._engines.values()), default=0)},
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         if others:

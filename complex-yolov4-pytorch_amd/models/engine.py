@@ -566,7 +566,9 @@ class Engine:
             r0 = ref.c0 - x.c0
             fl, by = self._conv_work(rec)
             fused = self._dgrad_sums.get((rec['idx'], ref.c0))
-            with ops.prof('igemm', fl * ref.C / x.C, by):
+            # (bench.py's launch brackets: a fused launch also reads the producer layer's pre-BN tensor)
+            with ops.prof('igemm_sums' if fused is not None else 'igemm', fl * ref.C / x.C,
+                          by + (self.view(ref, grad=True).M * ref.C * 2 if fused is not None else 0)):
                 if fused is not None:
                     # the sums of layer L go into the table L's backward will pick next (zeroed by the apply pass that just ran)
                     L, hint = fused

@@ -8,11 +8,13 @@ from .darknet2pytorch import Darknet
 
 
 def create_model(configs):
-    """Darknet built from ``configs.cfgfile``; ``configs.dtype`` ('f16' default / 'f32') picks the compute mode."""
+    """Darknet built from ``configs.cfgfile``; ``configs.dtype`` ('f16' default / 'bf16' / 'f32') picks the compute mode,
+    ``configs.deterministic`` (default False) the bit-reproducible reductions."""
     if configs.arch != 'darknet' or configs.cfgfile is None:
         raise AssertionError('Undefined model backbone')       # the reference asserts False here
     print('using darknet')
-    return Darknet(cfgfile=configs.cfgfile, use_giou_loss=configs.use_giou_loss, dtype=getattr(configs, 'dtype', 'f16'))
+    return Darknet(cfgfile=configs.cfgfile, use_giou_loss=configs.use_giou_loss, dtype=getattr(configs, 'dtype', 'f16'),
+                   deterministic=bool(getattr(configs, 'deterministic', False)))
 
 
 def get_num_parameters(model):

@@ -34,4 +34,11 @@ for k, d in agg.items():
     print(tag, k)
     for c, v in sorted(d.items()):
         print('   %-28s %14.0f per launch' % (c, v / max(1, cnt[(k, c)])))
+    if 'SQ_BUSY_CYCLES' in d and 'SQ_VALU_MFMA_BUSY_CYCLES' in d:
+        # SQ_BUSY_CYCLES sums the 32 shader engines' busy cycles; 1024 SIMDs = 32 per engine
+        busy = d['SQ_BUSY_CYCLES'] / cnt[(k, 'SQ_BUSY_CYCLES')]
+        mfma = d['SQ_VALU_MFMA_BUSY_CYCLES'] / cnt[(k, 'SQ_VALU_MFMA_BUSY_CYCLES')]
+        print('   => MFMA pipe busy %.1f %% of the kernel\'s SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES)); '
+              'LDS array active %.1f %% of CU-cycles' % (100 * mfma / (32 * busy),
+              100 * d.get('SQ_LDS_IDX_ACTIVE', 0) / max(1, cnt[(k, 'SQ_LDS_IDX_ACTIVE')]) / (8 * busy)))
 PY
