@@ -35,7 +35,10 @@ from complex_yolov4_pytorch_amd.utils.train_utils import create_optimizer  # noq
 CFG = os.path.join(ROOT, 'complex-yolov4-pytorch_amd', 'config', 'cfg', 'complex_yolov4.cfg')
 MFMA_PEAK_TFLOPS = {'f16': 2500.0, 'bf16': 2500.0, 'f32': 157.3}     # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 CONFIGS = {'train608': dict(kind='train', batch=16, size=608), 'infer32': dict(kind='infer', batch=32, size=608),
-           'train1024': dict(kind='train', batch=8, size=1024)}
+           'train1024': dict(kind='train', batch=8, size=1024),
+           # BASELINE configs[2]'s per-GPU work with "mosaic aug on" (reference kitti_dataset.py:123-173): every sample is a
+           # 1216 x 1216 canvas of four 608 x 608 BEV maps, built on the device inside the step from a resident pool
+           'train1216': dict(kind='train', batch=16, size=1216, mosaic=True)}
 HBM_PEAK_GBS = 8000.0
 HBM_PEAK_BPS = HBM_PEAK_GBS * 1e9
 
@@ -158,16 +161,44 @@ def measure_inference(dev, batch, size, dtype, steps, warmup):
                          '(256 candidates/image)' % (batch, size, size))
 
 
-def measure_train(dev, batch, size, dtype, steps, warmup):
+def batch_source(dev, batch, size, mosaic, seed=0):
+    """() -> (images [B,3,S,S], targets [nT,8]) on the device.  Plain: one resident synthetic batch.  mosaic: a resident pool
+    of 4*B maps of (S/2)^2 with 6 targets each; every call assembles B canvases with the device mosaic kernels
+    (data_process/transformation.py::make_mosaic, centre drawn per canvas like the reference's load_mosaic)."""
+    if not mosaic:
+        x, tg = syn.bev_images(batch, size, seed=seed).to(dev), syn.targets(batch, 6, size, seed=seed).to(dev)
+        return lambda: (x, tg)
+    import random
+    from complex_yolov4_pytorch_amd.data_process.transformation import make_mosaic
+    half = size // 2
+    pool = syn.bev_images(4 * batch, half, seed=seed).to(dev)
+    rows = syn.targets(4 * batch, 6, half, seed=seed)
+    per_tile = [rows[rows[:, 0] == i].clone() for i in range(4 * batch)]
+    rng = random.Random(seed)
+
+    def make():
+        random.seed(rng.random())
+        canvases, tgs = [], []
+        for b in range(batch):
+            c, t = make_mosaic([pool[4 * b + k] for k in range(4)], [per_tile[4 * b + k] for k in range(4)], half, random_padding=True)
+            t[:, 0] = b
+            canvases.append(c)
+            tgs.append(t)
+        return torch.stack(canvases), torch.cat(tgs, 0)
+    return make
+
+
+def measure_train(dev, batch, size, dtype, steps, warmup, mosaic=False):
     """A train step configuration measured briefly on one GPU (the `other_configs` entries of the default run)."""
     torch.manual_seed(0)
     model = Darknet(CFG, use_giou_loss=True, dtype=dtype).to(dev)
     model.train()
     opt = create_optimizer(_OptCfg, model)
-    x, tg = syn.bev_images(batch, size, seed=0).to(dev), syn.targets(batch, 6, size, seed=0).to(dev)
+    source = batch_source(dev, batch, size, mosaic)
 
     def step():
         opt.zero_grad(set_to_none=True)
+        x, tg = source()
         loss, _ = model(x, tg)
         loss.backward()
         opt.step()
@@ -187,7 +218,8 @@ def measure_train(dev, batch, size, dtype, steps, warmup):
     torch.cuda.empty_cache()
     return dict(metric='BEV images/s (%dx%d) train step' % (size, size), value=round(batch / dt, 2), unit='images/s',
                 ms_per_step=round(1e3 * dt, 3), steps=steps, dtype=dtype, loss_final=round(final, 4),
-                workload='complex_yolov4.cfg train step (fwd + rotated-GIoU loss + bwd + Adam), batch %d, %dx%d' % (batch, size, size))
+                workload='complex_yolov4.cfg train step (%sfwd + rotated-GIoU loss + bwd + Adam), batch %d, %dx%d'
+                         % ('device mosaic of four %dx%d maps per sample + ' % (size // 2, size // 2) if mosaic else '', batch, size, size))
 
 
 def main():
@@ -246,11 +278,11 @@ def main():
     model.train()
     net = RcclDataParallel(model) if (world > 1 or force_ddp) else model
     opt = create_optimizer(_OptCfg, model)          # FusedAdam (cy_adam_multi) on the device
-    x = syn.bev_images(a.batch, a.size, seed=rank).to(dev)
-    tg = syn.targets(a.batch, 6, a.size, seed=rank).to(dev)
+    source = batch_source(dev, a.batch, a.size, bool(cfg.get('mosaic')), seed=rank)
 
     def step():
         opt.zero_grad(set_to_none=True)
+        x, tg = source()
         loss, _ = net(x, tg)
         loss.backward()
         opt.step()
@@ -359,6 +391,7 @@ def main():
                       'train1024': measure_train(dev, 8, 1024, a.dtype, 5, 2)}
             if a.dtype == 'f16':
                 others['train608_bf16'] = measure_train(dev, 16, 608, 'bf16', 6, 3)
+            others['train1216_mosaic'] = measure_train(dev, 16, 1216, a.dtype, 3, 2, mosaic=True)
         if not a.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(2, a.size)
         imgs = world * a.batch * a.steps
@@ -367,8 +400,8 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * elapsed / a.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': 'complex_yolov4.cfg train step (fwd + rotated-GIoU loss + bwd + Adam), batch %d per GPU, %dx%dx3 synthetic BEV, 6 targets/image'
-                                   % (a.batch, a.size, a.size),
+            'config': {'workload': 'complex_yolov4.cfg train step (%sfwd + rotated-GIoU loss + bwd + Adam), batch %d per GPU, %dx%dx3 synthetic BEV, %d targets/image'
+                                   % ('device mosaic of four maps per sample + ' if cfg.get('mosaic') else '', a.batch, a.size, a.size, 24 if cfg.get('mosaic') else 6),
                        'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4),
                        'deterministic': bool(a.deterministic),
                        'dgrad_bn_sums_layers': max((len(e._sums_fused) for e in model._engines.values()), default=0)},

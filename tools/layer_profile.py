@@ -47,10 +47,17 @@ summ = p.summary()
 rows = sorted(summ.items(), key=lambda kv: -kv[1]['ms'])
 tot = sum(v['ms'] for v in summ.values())
 print('total conv-kernel ms/step %.2f (batch %d, %dx%d)' % (tot, B, S, S))
-print('%-6s %5s %5s %2s %1s %4s | %3s %8s %8s %8s %6s' % ('kind', 'cin', 'cout', 'k', 's', 'H', 'n', 'ms', 'TFLOP/s', 'GB/s', '%time'))
+# "floor": the launch at 4.5 TB/s of algorithmic bytes or 1500 TFLOP/s, whichever is longer (what a well-fed kernel reaches
+# on this chip); "lost" = time above it, summed over the shape's launches -- where the remaining conv time sits
+print('%-6s %5s %5s %2s %1s %4s | %3s %8s %8s %8s %6s %8s %8s' % ('kind', 'cin', 'cout', 'k', 's', 'H', 'n', 'ms', 'TFLOP/s', 'GB/s', '%time', 'us/launch', 'lost ms'))
+lost_tot = 0.0
 for (kind, cin, cout, ks, st, H), v in rows:
-    print('%-6s %5d %5d %2d %1d %4d | %3d %8.3f %8.1f %8.1f %6.2f' % (kind, cin, cout, ks, st, H, v['launches'], v['ms'],
-          v['flops'] / v['ms'] / 1e9, v['bytes'] / v['ms'] / 1e6, 100 * v['ms'] / tot))
+    floor = max(v['bytes'] / 4.5e12, v['flops'] / 1.5e15) * 1e3
+    lost = v['ms'] - floor
+    lost_tot += lost
+    print('%-6s %5d %5d %2d %1d %4d | %3d %8.3f %8.1f %8.1f %6.2f %8.1f %8.3f' % (kind, cin, cout, ks, st, H, v['launches'], v['ms'],
+          v['flops'] / v['ms'] / 1e9, v['bytes'] / v['ms'] / 1e6, 100 * v['ms'] / tot, 1e3 * v['ms'] / v['launches'], lost))
+print('time above the floor: %.2f ms of %.2f' % (lost_tot, tot))
 for kind in ('fwd', 'dgrad', 'wgrad'):
     ms = sum(v['ms'] for k, v in summ.items() if k[0] == kind); fl = sum(v['flops'] for k, v in summ.items() if k[0] == kind)
     print('%s: %.2f ms, %.1f TFLOP/s' % (kind, ms, fl / ms / 1e9))
