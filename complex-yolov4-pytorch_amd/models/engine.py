@@ -96,6 +96,8 @@ class Engine:
         self.bnpart_pair = [self.bnpart, torch.zeros(max_bnrows, **f32)] if (self.fused_bn and training) else None
         self._sp = self._bp = 0
         self.dgs, self.dbs = torch.empty(max_c, **f32), torch.empty(max_c, **f32)
+        # deterministic mode: second-stage table of the two-stage folds (<= 256 rows) / partial rows of the head bias gradient
+        self.fold_tmp = torch.zeros(max(256 * 2 * max_c, 256 * 32), **f32) if self.det else None
         # split-K slabs of every conv stay resident until their group is folded (table-driven, a few launches per step)
         self.wpart = torch.empty(max(max_wpart, 1), **f32)
         self._pack_table = self._pack_key = self._pack_epoch = None
@@ -270,7 +272,10 @@ class Engine:
             with ops.prof('igemm', *self._conv_work(rec)):
                 ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=self._stat_flags,
                                stats=self.stats, tile=self._fwd_tile.get(idx, 0))
-            ops.bn_finalize(self.stats, ops.conv_stats_rows(M, C, self.det), C, M, P[bname + '.weight'], P[bname + '.bias'],
+            tbl, rows = self.stats, ops.conv_stats_rows(M, C, self.det)
+            if rows > 256:       # deterministic mode on a large grid: one row per pixel tile -> two-stage fold
+                tbl, rows = self.fold_tmp, ops.fold_rows(self.stats, rows, 2 * C, self.fold_tmp)
+            ops.bn_finalize(tbl, rows, C, M, P[bname + '.weight'], P[bname + '.bias'],
                             P[bname + '.running_mean'], P[bname + '.running_var'],
                             P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, mean, invstd, scale, shift)
         else:
@@ -601,7 +606,10 @@ class Engine:
                 ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, tbl, rows)
         else:
             ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, self.bnpart, rows)
-            ops.bn_bwd_finalize(self.bnpart, rows, C, self.dgs, self.dbs,
+            ftbl, frows = self.bnpart, rows
+            if rows > 256:
+                ftbl, frows = self.fold_tmp, ops.fold_rows(self.bnpart, rows, 2 * C, self.fold_tmp)
+            ops.bn_bwd_finalize(ftbl, frows, C, self.dgs, self.dbs,
                                 self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls)
         res_view, res_acc = None, False
         runs = b['res_runs']
@@ -627,8 +635,11 @@ class Engine:
         M, nch = self.N * hd['G'] * hd['G'], hd['A'] * (7 + hd['C'])
         tmp = self.head_tmp[h]
         ops.f32_to_view(self.dlogits[h], M, nch, self.act_scale, tmp, 32, scale_dev=self.gout)
-        ops.bias_grad(self.dlogits[h], M, nch, self.act_scale / self.ls, self.grads[cname + '.bias'], scale_dev=self.gout,
-                      deterministic=self.det)
+        if self.det:
+            ops.bias_grad_det(self.dlogits[h], M, nch, self.act_scale / self.ls, self.grads[cname + '.bias'], self.fold_tmp,
+                              scale_dev=self.gout)
+        else:
+            ops.bias_grad(self.dlogits[h], M, nch, self.act_scale / self.ls, self.grads[cname + '.bias'], scale_dev=self.gout)
         self._wgrad(rec, tmp, self.view(rec['x']))
         self._dgrad(rec, tmp, b['dx'])
 

@@ -398,6 +398,21 @@ def bn_act_bwd_apply_fused(x, dy, dx, res_grad, res_accum, mean, invstd, scale, 
                zero_table.numel() if zero_table is not None else 0, act, x.dt, _stream())
 
 
+def fold_rows_out(rows):
+    return lib().raw('cy_fold_rows_out')(rows)
+
+
+def fold_rows(bins, rows, W, out):
+    """Deterministic mode: first stage of the two-stage fold; -> rows of ``out`` to hand to the finaliser."""
+    ro = fold_rows_out(rows)
+    lib().call('cy_fold_rows', _p(bins), rows, W, _p(out), ro, _stream())
+    return ro
+
+
+def bias_grad_det(dlogits, M, C, scale, gbias, scratch, scale_dev=None):
+    lib().call('cy_bias_grad_det', _p(dlogits), M, C, float(scale), _p(scale_dev), _p(gbias), _p(scratch), _stream())
+
+
 def bn_bwd_rows(M, C, dt, det=False):
     return lib().raw('cy_bn_bwd_rows_det' if det else 'cy_bn_bwd_rows')(M, C, dt)
 

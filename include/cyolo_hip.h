@@ -249,6 +249,17 @@ int cy_f32_to_view(const float* x, int64_t M, int C, float scale, const float* s
 int cy_bias_grad(const float* dlogits, int64_t M, int C, float scale, const float* scale_dev, float* gbias,
                  int deterministic, cy_stream_t s);
 
+/* Deterministic mode of the same: per-block partial rows into `scratch` (>= 256 * 32 floats), folded in block order by a
+ * second one-block launch -- no float atomics, the sum does not depend on scheduling. */
+int cy_bias_grad_det(const float* dlogits, int64_t M, int C, float scale, const float* scale_dev, float* gbias,
+                     float* scratch, cy_stream_t s);
+/* Deterministic mode, first stage of a two-stage fold of a partial-sum table: bins [rows][W] (W = 2 * C for the BatchNorm
+ * tables) -> out [rows_out][W], slice k = rows [k RS, (k+1) RS) with RS = ceil(rows / rows_out), summed in row order; the
+ * rows read are zeroed.  rows_out = cy_fold_rows_out(rows) (= rows up to 256, else <= 128).  The finalisers
+ * (cy_bn_finalize / cy_bn_bwd_finalize) then take (out, rows_out) instead of (bins, rows). */
+int cy_fold_rows(float* bins, int rows, int W, float* out, int rows_out, cy_stream_t s);
+int cy_fold_rows_out(int rows);
+
 /* ------------------------------------------------------------------------------------------------
  * YOLO head  (reference models/yolo_layer.py)
  * ---------------------------------------------------------------------------------------------- */

@@ -205,6 +205,17 @@ def bn_act_bwd_reduce(x, dy, mean, invstd, scale, shift, act, part, rows=None):
     p[0, 1] = (dz * xh).sum((0, 2, 3))
 
 
+def fold_rows(bins, rows, W, out):
+    p = bins.view(-1)[:rows * W].view(rows, W)
+    out.view(-1)[:W] = p.sum(0)
+    p.zero_()
+    return 1
+
+
+def bias_grad_det(dlogits, M, C, scale, gbias, scratch, scale_dev=None):
+    bias_grad(dlogits, M, C, scale, gbias, scale_dev=scale_dev)
+
+
 def bn_bwd_finalize(part, rows, C, dgs, dbs, ggamma, gbeta, gscale):
     p = part.view(-1)[:rows * 2 * C].view(rows, 2, C).sum(0)
     part.view(-1)[:rows * 2 * C].zero_()
@@ -314,7 +325,7 @@ NAMES = ['check_device_tensor', 'nchw_to_nhwc', 'pack_weights_into', 'make_pack_
          'make_reduce_table', 'wgrad_reduce_multi', 'conv_bn_act_eval', 'conv_igemm', 'conv_dgrad_bn_sums', 'conv_wgrad', 'wgrad_reduce',
          'bn_finalize', 'bn_eval_affine', 'bn_act_fwd', 'bn_act_fwd_fused', 'bn_act_bwd_apply_fused', 'bn_act_bwd_reduce', 'bn_bwd_finalize', 'bn_act_bwd_apply',
          'maxpool_argmax_bytes', 'maxpool_fwd', 'maxpool_bwd', 'upsample_fwd', 'upsample_bwd', 'slice_copy', 'slice_add', 'f32_to_view',
-         'zero_view', 'bias_grad', 'yolo_decode', 'yolo_loss']
+         'zero_view', 'bias_grad', 'bias_grad_det', 'fold_rows', 'yolo_decode', 'yolo_loss']
 
 
 def install(monkeypatch):

@@ -397,3 +397,38 @@ def test_model_backward_with_dgrad_sums_matches_separate_reduce(monkeypatch, dty
     noise = float((a0 - a1).norm() / a0.norm())
     diff = float((b - a0).norm() / a0.norm())
     assert diff < max(3 * noise, 2e-2), (diff, noise)
+
+
+def test_two_stage_deterministic_folds():
+    """cy_fold_rows (+ finaliser on its output) = finaliser on the full table; cy_bias_grad_det = cy_bias_grad; both are
+    bit-identical from call to call."""
+    g = torch.Generator().manual_seed(9)
+    rows, C, M = 5000, 64, 5000 * 64
+    table = torch.randn(rows, 2, C, generator=g).to(DEV)
+    table[:, 1] = table[:, 1].abs() * 64 + 70.0 * 64        # second moments: large enough for a positive variance
+    gamma, beta = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV)
+    outs = []
+    for two_stage in (False, True, True):
+        t = table.clone()
+        vec = torch.empty(4, C, device=DEV)
+        tbl, r = t, rows
+        if two_stage:
+            tmp = torch.zeros(256 * 2 * C, device=DEV)
+            r = ops.fold_rows(t, rows, 2 * C, tmp)
+            assert r == ops.fold_rows_out(rows) <= 128 and float(t.abs().max()) == 0.0      # the rows read are zeroed
+            tbl = tmp
+        ops.bn_finalize(tbl, r, C, M, gamma, beta, None, None, None, 0.1, 1e-5, vec[0], vec[1], vec[2], vec[3])
+        outs.append(vec)
+    torch.testing.assert_close(outs[1], outs[0], rtol=1e-5, atol=1e-6)
+    assert torch.equal(outs[1], outs[2])
+    d = torch.randn(76 * 76 * 4 * 30, generator=g).to(DEV)
+    Mh = 76 * 76 * 4
+    ref = torch.ones(30, device=DEV)
+    ops.bias_grad(d, Mh, 30, 0.5, ref)
+    got = []
+    for _ in range(2):
+        gb = torch.ones(30, device=DEV)
+        ops.bias_grad_det(d, Mh, 30, 0.5, gb, torch.empty(256 * 32, device=DEV))
+        got.append(gb)
+    torch.testing.assert_close(got[0], ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(got[0], got[1])
