@@ -379,6 +379,7 @@ def main():
     if world > 1:
         dist.barrier()
 
+    fused_layers = max((len(e._sums_fused) for e in model._engines.values()), default=0)
     if rank == 0:
         cpu = None
         others = None
@@ -404,7 +405,7 @@ def main():
                                    % ('device mosaic of four maps per sample + ' if cfg.get('mosaic') else '', a.batch, a.size, a.size, 24 if cfg.get('mosaic') else 6),
                        'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4),
                        'deterministic': bool(a.deterministic),
-                       'dgrad_bn_sums_layers': max((len(e._sums_fused) for e in model._engines.values()), default=0)},
+                       'dgrad_bn_sums_layers': fused_layers},
             'roofline': roofline, 'cpu_baseline': cpu,
         }
         if others:
