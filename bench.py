@@ -47,6 +47,18 @@ class _OptCfg:
     optimizer_type, lr, momentum, weight_decay = 'adam', 1e-3, 0.949, 5e-4     # reference train_config.py:82-94
 
 
+def emit(line):
+    """The ONE JSON line, last on stdout: RCCL writes its version banner through C stdio, which would otherwise be flushed
+    after Python's buffer at exit -- flush both first."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(line), flush=True)
+
+
 def usable_cores(cap=32):
     """Cores this process may really use: affinity mask and cgroup CPU quota, capped (oversubscribed OpenMP teams on
     a 256-thread host made a single oracle step take minutes)."""
@@ -263,14 +275,16 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if rank == 0:
             ms = float(t)
-            print(json.dumps({'metric': r['metric'], 'value': round(world * a.batch / (ms * 1e-3), 3), 'unit': 'images/s',
-                              'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
-                              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
-                              'data': 'synthetic', 'config': {'workload': r['workload'], 'global_batch': world * a.batch,
-                                                              'parallelism': 'replicas%d' % world},
-                              'roofline': None, 'cpu_baseline': None}))
+            line = {'metric': r['metric'], 'value': round(world * a.batch / (ms * 1e-3), 3), 'unit': 'images/s',
+                    'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms, 3),
+                    'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
+                    'data': 'synthetic', 'config': {'workload': r['workload'], 'global_batch': world * a.batch,
+                                                    'parallelism': 'replicas%d' % world},
+                    'roofline': None, 'cpu_baseline': None}
         if dist.is_initialized():
             dist.destroy_process_group()
+        if rank == 0:
+            emit(line)
         return
 
     torch.manual_seed(0)
@@ -410,9 +424,10 @@ def main():
         }
         if others:
             line['other_configs'] = others
-        print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        emit(line)
 
 
 if __name__ == '__main__':
