@@ -1,0 +1,289 @@
+// Direct 3x3 convolution for the small-Cin forward layers of the Darknet stack (reference darknet2pytorch.py:247-278):
+// 3 -> 32 @608 (Cin padded to 8), 32 -> 64 stride 2 @608 -> 304 and 32 -> 64 @304.  K = 9 * Cin is 72 or 288: per pixel
+// the GEMM is a handful of MFMAs and the layers are pure streaming -- the implicit-GEMM kernels spend their time on per-block
+// prologues, K-step barriers and a 9-fold gather through the load path (rocprofv3, batch 32 inference: 752 + 2 x 636 us for
+// these three launches, 18 % of the step, against HBM floors of 190 / 230 / 115 us).
+//
+// One persistent block per CU slot loops over output tiles of TH x TW pixels of one image:
+//   * the packed weights [Cout][9 * Cin] sit in LDS for the life of the block (rows padded by 16 bytes: conflict-free A reads);
+//   * the input patch ((TH-1) S + 3) x ((TW-1) S + 3) x Cin is read ONCE, 16 bytes per lane, zero outside the image;
+//   * a wave computes 32-pixel row segments: the B fragment of MFMA step j is one ds_read_b128 of the patch at the pixel
+//     shifted by the step's tap (k = tap * Cin + c: a 16-byte chunk = 8 channels of one tap) -- no im2col image;
+//   * epilogue like conv_pipe.hip: BN batch statistics (32-lane sums, one atomic per channel, moment and block), or the
+//     eval-mode affine + activation (+ shortcut); the accumulators are transposed through LDS and stored 16 bytes per lane.
+#include "igemm_common.hpp"
+
+namespace {
+using namespace cyk;
+
+template <typename T, int CIN, int COUT, int S, int TH, int TW, int SPW>
+struct DirectCfg {
+    static constexpr int NSEG = TH * (TW / 32), NWAVE = NSEG / SPW, NT = NWAVE * 64;
+    static constexpr int PR = (TH - 1) * S + 3, PC = (TW - 1) * S + 3;   // patch rows / columns
+    static constexpr int PXB = CIN * 2, CPP = CIN / 8;                     // bytes / 16-byte chunks per patch pixel
+    static constexpr int K = 9 * CIN, KS = (K + 15) / 16;                  // reduction length, MFMA steps
+    static constexpr int WROW = K * 2 + 16;                                // weight row in LDS (one chunk of padding, zeroed)
+    static constexpr int NCB = COUT / 32;
+    static constexpr int W_BYTES = COUT * WROW;
+    static constexpr int SROW = COUT * 4 + 16;                             // fp32 store-tile row (padded: spreads the banks)
+    static constexpr int ST_BYTES = NWAVE * 32 * SROW;                     // wave-private [32 pixels][COUT] fp32 tiles ...
+    static constexpr int PATCH_BYTES = (PR * PC * PXB + 15) / 16 * 16;
+    static constexpr int P_BYTES = PATCH_BYTES > ST_BYTES ? PATCH_BYTES : ST_BYTES;   // ... which reuse the patch's LDS
+    static constexpr int RED_BYTES = NWAVE * 2 * COUT * 4 + 2 * COUT * 4;   // block reduction of the statistics + (scale, shift)
+    static constexpr int SMEM = W_BYTES + P_BYTES + RED_BYTES;
+    static constexpr int BLOCKS_PER_CU = SMEM > 40 * 1024 ? 2 : 4;
+    static_assert(NSEG % SPW == 0 && TW % 32 == 0 && (CIN == 8 || CIN == 32) && COUT % 32 == 0, "tile layout");
+};
+
+// physical 16-byte chunk of logical chunk c of patch column pcol (Cin = 32: four chunks per pixel, spread so that 16
+// consecutive columns hit 16 distinct bank groups)
+template <int CPP>
+__device__ __forceinline__ int pswz(int c, int pcol) {
+    return CPP == 1 ? 0 : (c ^ (pcol & 3) ^ ((pcol >> 2) & 3));
+}
+
+template <typename T, int CIN, int COUT, int S, int TH, int TW, int SPW>
+__global__ void __launch_bounds__((TH * (TW / 32) / SPW) * 64, (DirectCfg<T, CIN, COUT, S, TH, TW, SPW>::BLOCKS_PER_CU))
+    direct3x3_kernel(const IgemmParams p) {
+    typedef DirectCfg<T, CIN, COUT, S, TH, TW, SPW> C;
+    typedef typename Mma32<T>::frag frag;
+    typedef T tx4 __attribute__((ext_vector_type(4)));
+    typedef T tx8 __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;
+    unsigned char* patch = smem + C::W_BYTES;
+    unsigned char* stage = patch;          // reused once every wave is done reading the patch
+    float* red = reinterpret_cast<float*>(patch + C::P_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // ---- weights -> LDS (once per block) ---------------------------------------------------------------------------------
+    {
+        constexpr int CPRW = C::K * 2 / 16;          // 16-byte chunks per weight row
+        for (int idx = tid; idx < COUT * (CPRW + 1); idx += C::NT) {
+            const int row = idx / (CPRW + 1), ch = idx - row * (CPRW + 1);
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (ch < CPRW && row < p.wrows) v = *reinterpret_cast<const u32x4*>(p.w + (size_t)row * (C::K * 2) + ch * 16);
+            *reinterpret_cast<u32x4*>(wl + row * C::WROW + ch * 16) = v;
+        }
+    }
+    const int tiles_x = (p.OW + TW - 1) / TW, tiles_y = (p.OH + TH - 1) / TH;
+    const int ntiles = p.N * tiles_y * tiles_x;
+    const bool stats = (p.flags & CY_CONV_STATS) != 0, affine = (p.flags & CY_CONV_AFFINE_ACT) != 0;
+    constexpr int NSB = (COUT + 63) / 64;
+    float ssum[NSB], qsum[NSB];            // lane c: channel sb*64 + c
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) { ssum[sb] = 0.f; qsum[sb] = 0.f; }
+    // eval epilogue: the BN affine of the layer, in LDS behind the reduction scratch (read per accumulator register)
+    float* asc = red + C::NWAVE * 2 * COUT;
+    float* ash = asc + COUT;
+    if (affine)
+        for (int c = tid; c < COUT; c += C::NT) { asc[c] = p.aff_scale[min(c, p.OC - 1)]; ash[c] = p.aff_shift[min(c, p.OC - 1)]; }
+    const size_t pixg = (size_t)p.ldg * 2, pixo = (size_t)p.ldo * 2;
+
+    // The patch of the NEXT tile is requested into registers before this tile's MFMAs and epilogue and written to LDS after
+    // them: its memory latency hides behind a whole tile of work (two blocks per CU alone could not hide it).
+    constexpr int NCH = C::PR * C::PC * C::CPP, NIT = (NCH + C::NT - 1) / C::NT;
+    u32x4 pre[NIT];
+    auto issue = [&](int tile) {
+        const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
+        const int iy0 = (tr / tiles_x) * TH * S - 1, ix0 = (tr % tiles_x) * TW * S - 1;
+        const unsigned char* gimg = p.g + (size_t)n * p.GH * p.GW * pixg;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * C::NT + tid;
+            const int c = idx % C::CPP, pp = idx / C::CPP;
+            const int prow = pp / C::PC, pcol = pp - prow * C::PC;
+            const int iy = iy0 + prow, ix = ix0 + pcol;
+            pre[it] = u32x4{0u, 0u, 0u, 0u};
+            if (idx < NCH && (unsigned)iy < (unsigned)p.GH && (unsigned)ix < (unsigned)p.GW)
+                pre[it] = *reinterpret_cast<const u32x4*>(gimg + ((size_t)iy * p.GW + ix) * pixg + c * 16);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
+        const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+        __syncthreads();      // the previous tile's store tiles (same LDS) are done; first trip: weights / affine in place after the next one
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * C::NT + tid;
+            const int c = idx % C::CPP, pp = idx / C::CPP;
+            const int pcol = pp % C::PC;
+            if (idx < NCH) *reinterpret_cast<u32x4*>(patch + pp * C::PXB + pswz<C::CPP>(c, pcol) * 16) = pre[it];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        // ---- MFMA over the wave's segments ---------------------------------------------------------------------------------
+        f32x16 acc[SPW][C::NCB];
+#pragma unroll
+        for (int s = 0; s < SPW; ++s)
+#pragma unroll
+            for (int cb = 0; cb < C::NCB; ++cb)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[s][cb][t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < C::KS; ++j) {
+            // this lane's 8 reduction indices of step j: k0 = j*16 + half*8 -> (tap, first channel)
+            const int k0 = j * 16 + half * 8;
+            int tap = k0 / CIN;
+            const int cch = (k0 - tap * CIN) / 8;
+            if (tap > 8) tap = 0;              // K tail of the Cin = 8 layer: the weights there are zero, the data must be finite
+            const int kh = tap / 3, kw = tap - kh * 3;
+            frag a[C::NCB];
+#pragma unroll
+            for (int cb = 0; cb < C::NCB; ++cb)
+                a[cb] = *reinterpret_cast<const frag*>(wl + (cb * 32 + l31) * C::WROW + j * 32 + half * 16);
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                const int seg = wave * SPW + s;
+                const int sy = seg / (TW / 32), sx = (seg % (TW / 32)) * 32;
+                const int prow = sy * S + kh, pcol = (sx + l31) * S + kw;
+                const frag b = *reinterpret_cast<const frag*>(patch + (prow * C::PC + pcol) * C::PXB + pswz<C::CPP>(cch, pcol) * 16);
+#pragma unroll
+                for (int cb = 0; cb < C::NCB; ++cb) acc[s][cb] = Mma32<T>::mma(a[cb], b, acc[s][cb]);
+            }
+        }
+        __syncthreads();      // every wave is done with the patch: its LDS becomes the store tiles
+        // ---- epilogue: lane holds D[co = cb*32 + 8g + 4*half + r][pixel l31 of the segment], register 4g + r -----------------
+        unsigned char* wst = stage + wave * (32 * C::SROW);
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const int seg = wave * SPW + s;
+            const int oy = y0 + seg / (TW / 32), oxs = x0 + (seg % (TW / 32)) * 32;
+            const int nvalid = oy < p.OH ? min(32, max(0, p.OW - oxs)) : 0;       // pixels of this segment inside the image
+            // accumulators (eval: after affine + activation) -> the wave's fp32 tile [pixel][channel]
+#pragma unroll
+            for (int cb = 0; cb < C::NCB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[s][cb][4 * g + r];
+                        if (affine) {
+                            const int co = cb * 32 + 8 * g + 4 * half + r;
+                            const float z = v * asc[co] + ash[co];
+                            const float zm = mish_f<true>(z), zl = z > 0.f ? z : 0.1f * z;
+                            v = p.act == CY_ACT_MISH ? zm : (p.act == CY_ACT_LEAKY ? zl : z);
+                        }
+                        h[r] = v;
+                    }
+                    *reinterpret_cast<f32x4*>(wst + l31 * C::SROW + (cb * 32 + 8 * g + 4 * half) * 4) = h;
+                }
+            // (wave-private tile: the wave's own ds_writes are ordered before its ds_reads by lgkmcnt)
+            if (stats) {
+                // BatchNorm statistics of the fp32 accumulators: lane c sums column c over the valid pixel rows
+#pragma unroll
+                for (int cb = 0; cb < (COUT + 63) / 64; ++cb) {
+                    const int c = cb * 64 + lane;
+                    if (c < COUT) {
+                        float sv = 0.f, qv = 0.f;
+                        for (int r = 0; r < nvalid; ++r) {
+                            const float v = *reinterpret_cast<const float*>(wst + r * C::SROW + c * 4);
+                            sv += v;
+                            qv += v * v;
+                        }
+                        ssum[cb] += sv;
+                        qsum[cb] += qv;
+                    }
+                }
+            }
+            constexpr int CPO = COUT / 8;                 // 16-byte chunks per output pixel
+#pragma unroll
+            for (int it = 0; it < 32 * CPO / 64; ++it) {
+                const int idx = it * 64 + lane, px = idx / CPO, ch = idx - px * CPO;
+                if (px >= nvalid || ch * 8 >= p.OC) continue;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(wst + px * C::SROW + ch * 32);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(wst + px * C::SROW + ch * 32 + 16);
+                float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const size_t opix = ((size_t)n * p.OH + oy) * p.OW + oxs + px;
+                if (affine && p.res) {
+                    const tx8 rv = *reinterpret_cast<const tx8*>(reinterpret_cast<const T*>(p.res) + opix * p.ldres + ch * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += (float)rv[e];
+                }
+                tx8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (T)f[e];
+                *reinterpret_cast<tx8*>(p.o + opix * pixo + ch * 16) = v;
+            }
+        }
+    }
+    if (stats) {
+        // per block: one fp32 atomic per (channel, moment) into one of the CY_STAT_BINS rows
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+            const int c = sb * 64 + lane;
+            if (c < COUT) {
+                red[(wave * 2 + 0) * COUT + c] = ssum[sb];
+                red[(wave * 2 + 1) * COUT + c] = qsum[sb];
+            }
+        }
+        __syncthreads();
+        float* srow = p.stats + (size_t)(blockIdx.x & (CY_STAT_BINS - 1)) * 2 * p.OC;
+        for (int c = tid; c < 2 * COUT; c += C::NT) {
+            const int mom = c / COUT, co = c - mom * COUT;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::NWAVE; ++w) t += red[(w * 2 + mom) * COUT + co];
+            if (co < p.OC) atomicAdd(srow + mom * p.OC + co, t);
+        }
+    }
+}
+
+template <typename T, int CIN, int COUT, int S, int TH, int TW, int SPW>
+int direct_launch(const IgemmParams& p, hipStream_t s) {
+    typedef DirectCfg<T, CIN, COUT, S, TH, TW, SPW> C;
+    static_assert(C::SMEM <= 80 * 1024, "two blocks per CU");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct3x3_kernel<T, CIN, COUT, S, TH, TW, SPW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        attr_done = true;
+    }
+    const long tiles = (long)p.N * ((p.OH + TH - 1) / TH) * ((p.OW + TW - 1) / TW);
+    const int slots = 256 * C::BLOCKS_PER_CU;                     // persistent blocks: every CU slot, each looping over tiles
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    hipLaunchKernelGGL((direct3x3_kernel<T, CIN, COUT, S, TH, TW, SPW>), dim3(grid), dim3(C::NT), C::SMEM, s, p);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int direct_dispatch(const IgemmParams& p, hipStream_t s, int* used) {
+    *used = 1;
+    if (p.GC == 8 && p.OC == 32 && p.stride == 1) return direct_launch<T, 8, 32, 1, 4, 64, 2>(p, s);
+    if (p.GC == 32 && p.OC == 64 && p.stride == 1) return direct_launch<T, 32, 64, 1, 4, 64, 2>(p, s);
+    if (p.GC == 32 && p.OC == 64 && p.stride == 2) return direct_launch<T, 32, 64, 2, 4, 32, 1>(p, s);
+    *used = 0;
+    return 0;
+}
+
+}  // namespace
+
+static int g_direct_mode = -1;
+static int64_t g_direct_launches = 0;
+
+extern "C" int64_t cy_direct_launches(void) { return g_direct_launches; }
+
+// Which launches take the direct kernel: 16-bit forward 3x3 convs with pad 1 of the three instantiated (Cin, Cout, stride)
+// shapes, whole-tensor views (every (Cin, Cout) chunk aligned), BN statistics into shared bins or the eval-mode epilogue.
+// CY_CONV_TILE(1) keeps a call on the 4-wave kernels (A/B and the autotuner's baseline); CY_CONV_DIRECT=0 switches it off.
+int cy_direct_try(const cyk::IgemmParams& p, int dtype, hipStream_t s, int* used) {
+    *used = 0;
+    if (g_direct_mode < 0) {
+        const char* e = getenv("CY_CONV_DIRECT");
+        g_direct_mode = e ? atoi(e) : 1;
+    }
+    const int hint = (p.flags >> CY_CONV_TILE_SHIFT) & 15;
+    if (!g_direct_mode || hint == 1 || (dtype != CY_F16 && dtype != CY_BF16)) return 0;
+    if (p.ks != 3 || p.pad != 1 || p.transposed || p.stat_det) return 0;
+    if (p.flags & (CY_CONV_BIAS_F32OUT | CY_CONV_ACCUM | CY_CONV_BNBWD_SUMS)) return 0;
+    if (p.ldg % 8 || p.ldo % 8 || ((uintptr_t)p.g & 15) || ((uintptr_t)p.o & 15) || ((uintptr_t)p.w & 15)) return 0;
+    if (p.res && (p.ldres % 8 || ((uintptr_t)p.res & 15))) return 0;
+    if (p.OH != (p.GH + 2 - 3) / p.stride + 1 || p.OW != (p.GW + 2 - 3) / p.stride + 1) return 0;
+    const int rc = dtype == CY_F16 ? direct_dispatch<f16>(p, s, used) : direct_dispatch<bf16>(p, s, used);
+    if (rc == 0 && *used) ++g_direct_launches;
+    return rc;
+}

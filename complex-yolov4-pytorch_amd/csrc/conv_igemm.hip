@@ -425,7 +425,9 @@ int dispatch_tiles(const IgemmParams& p, hipStream_t s) {
 // one launch: the pipelined kernel when the shape qualifies, else the 4-wave kernels of this file
 int dispatch(const IgemmParams& p, int dtype, hipStream_t s) {
     int used = 0;
-    const int rc = cy_pipe_try(p, dtype, s, &used);
+    int rc = cy_direct_try(p, dtype, s, &used);
+    if (rc || used) return rc;
+    rc = cy_pipe_try(p, dtype, s, &used);
     if (rc || used) return rc;
     if (p.flags & CY_CONV_BNBWD_SUMS) return CY_ERR_ARG;   // only the pipelined kernel has that epilogue
     if (dtype == CY_F16) return dispatch_tiles<f16>(p, s);

@@ -23,31 +23,6 @@
 namespace {
 using namespace cyk;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <typename T>
-struct Mma32;
-template <>
-struct Mma32<f16> {
-    typedef f16x8 frag;
-    __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-};
-template <>
-struct Mma32<bf16> {
-    typedef bf16x8 frag;
-    __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-
-// sum over the 32 lanes of a half wave that share lane >> 5 (every lane of the half ends up with the total)
-__device__ __forceinline__ float half32_sum(float v) {
-    v = row16_sum(v);
-    return v + __shfl_xor(v, 16, 64);
-}
-
 // LOADERS = 0: the eight waves stage their own share of every tile.  LOADERS = 4: four extra waves (one per SIMD) do
 // nothing but issue the DMA pieces and their scalar / vector address arithmetic, the eight compute waves nothing but
 // fragment reads and MFMAs: with two waves per SIMD the ~100 cycles a wave spends issuing each buffer_load ... lds

@@ -93,6 +93,32 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// ---- 32 x 32 x 16 fragments (conv_pipe.hip, conv_direct.hip) ------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T>
+struct Mma32;
+template <>
+struct Mma32<f16> {
+    typedef f16x8 frag;
+    __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Mma32<bf16> {
+    typedef bf16x8 frag;
+    __device__ static __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+// sum over the 32 lanes of a half wave that share lane >> 5 (every lane of the half ends up with the total)
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16, 64);
+}
+
 // Epilogue of a BN-channel x BM-pixel block tile held as 16x16 accumulator fragments:
 // lane holds D[co = cbase + i*16 + (lane>>4)*4 + r][pixel = mbase + j*16 + (lane&15)].
 // NW waves = 2 over channels x NW/2 over pixels.  smem: the block's LDS (free for reuse; SYNC_FIRST adds the barrier
@@ -230,3 +256,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 // conv_pipe.hip: launches the pipelined kernel when the shape qualifies (*used = 1), else leaves the launch to
 // conv_igemm.hip (*used = 0).
 int cy_pipe_try(const cyk::IgemmParams& p, int dtype, hipStream_t s, int* used);
+// conv_direct.hip: the small-Cin 3x3 forward layers (3 -> 32, 32 -> 64) as a direct convolution over an LDS-resident input
+// patch (*used = 1), everything else (*used = 0) stays with the implicit-GEMM kernels.
+int cy_direct_try(const cyk::IgemmParams& p, int dtype, hipStream_t s, int* used);

@@ -188,6 +188,17 @@ class Engine:
         else:
             self._pack_epoch = None
         ops.pack_weights_multi(self._pack_table[0], self._pack_table[1], self.dt)
+        if not self.training:
+            # eval: BatchNorm is an affine of the running statistics; its (scale, shift) vectors change exactly when the packed
+            # weights do, so they are refreshed here (107 five-microsecond launches per forward otherwise: 4.5 % of the
+            # batch-32 inference step)
+            P = self.params
+            for rec in self.plan.convs:
+                if rec['bn']:
+                    _, bname = self._names(rec)
+                    vec = self.bnvec[rec['idx']]
+                    ops.bn_eval_affine(P[bname + '.weight'], P[bname + '.bias'], P[bname + '.running_mean'],
+                                       P[bname + '.running_var'], BN_EPS, vec[2], vec[3])
 
     def _build_reduce_groups(self):
         """Partition the convs (backward order) into fold groups, one launch per group.  A fold costs its slab bytes, and
@@ -281,9 +292,7 @@ class Engine:
         else:
             # eval: BN is an affine of the running statistics -> conv + BN + activation (+ shortcut) in one kernel,
             # the pre-BN tensor is never materialised
-            ops.bn_eval_affine(P[bname + '.weight'], P[bname + '.bias'], P[bname + '.running_mean'],
-                               P[bname + '.running_var'], BN_EPS, scale, shift)
-            res = self.view(rec['res']) if rec['res'] is not None else None
+            res = self.view(rec['res']) if rec['res'] is not None else None     # (scale, shift): refreshed by _pack_all
             with ops.prof('igemm', *self._conv_work(rec)):
                 ops.conv_bn_act_eval(xv, self.wf[idx], cop, self.view(rec['out']), rec['ks'], rec['stride'], rec['pad'],
                                      scale, shift, ops.ACT[rec['act']], res, tile=self._fwd_tile.get(idx, 0))
@@ -428,19 +437,21 @@ class Engine:
         return (getattr(self.device, 'type', str(self.device)) == 'cuda' and self.dt != CY_F32 and hasattr(ops, 'CONV_TILE_HINTS')
                 and os.environ.get('CY_CONV_AUTOTUNE', '1') != '0')
 
-    def _time_hints(self, key, launch, cin, cout):
+    def _time_hints(self, key, launch, cin, cout, ks=0):
         """Best kernel / tile hint for one conv launch shape: time every candidate (1 warm-up + 3 launches between HIP
         events) and keep the fastest.  The 4-wave and the 8-wave kernels are within +-10 % of each other on v4's layers and
         the winner depends on how tiles quantise over the 256 CUs, so it is measured, once per shape and process."""
-        return self._time_hints_t(key, launch, cin, cout)[0]
+        return self._time_hints_t(key, launch, cin, cout, ks=ks)[0]
 
-    def _time_hints_t(self, key, launch, cin, cout, pipe_only=False):
+    def _time_hints_t(self, key, launch, cin, cout, pipe_only=False, ks=0):
         """-> (best hint, its time in ms for 3 launches); pipe_only leaves the 4-wave kernels out and returns (None, None)
         when the pipelined kernel does not take the shape."""
         memo = _CONV_TUNE_MEMO.get(key)
         if memo is not None:
             return memo
         hints = [] if pipe_only else [1]
+        if ks == 3 and cin in (8, 32) and not pipe_only:
+            hints.append(0)       # forward 3 -> 32 / 32 -> 64: the library default is the direct small-Cin kernel (conv_direct.hip)
         if cin % 64 == 0 and cout % 8 == 0:
             hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h in (3, 8) and cout <= 64)]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -477,7 +488,7 @@ class Engine:
                 key = ('fwd', self.dt, self.det, xv.N, xv.H, xv.W, xv.C, xv.ld, raw.C, raw.ld, rec['ks'], rec['stride'])
                 self._fwd_tile[idx] = self._time_hints(key, lambda h: ops.conv_igemm(
                     xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=self._stat_flags, stats=self.stats,
-                    tile=h), xv.C, raw.C)
+                    tile=h), xv.C, raw.C, ks=rec['ks'])
             else:
                 out = self.view(rec['out'])
                 res = self.view(rec['res']) if rec['res'] is not None else None
@@ -485,7 +496,7 @@ class Engine:
                 key = ('eval', self.dt, xv.N, xv.H, xv.W, xv.C, xv.ld, out.C, out.ld, rec['ks'], rec['stride'], res is not None)
                 self._fwd_tile[idx] = self._time_hints(key, lambda h: ops.conv_bn_act_eval(
                     xv, self.wf[idx], cop, out, rec['ks'], rec['stride'], rec['pad'], vec[2], vec[3], ops.ACT[rec['act']], res,
-                    tile=h), xv.C, out.C)
+                    tile=h), xv.C, out.C, ks=rec['ks'])
         self.stats.zero_()        # the timed launches added into the statistics table
         if self.stats_pair is not None:
             self.stats_pair[1].zero_()

@@ -308,6 +308,11 @@ def pipe_launches():
     return int(lib().raw('cy_pipe_launches')())
 
 
+def direct_launches():
+    """Kernel launches since load that ran on the direct small-Cin 3x3 kernel (cy_direct_launches)."""
+    return int(lib().raw('cy_direct_launches')())
+
+
 def conv_pipe_config(mode=1, cap=0, bn=0, variant=0, bm_eff=0):
     """Tuning / A-B switch of the conv dispatch (cy_conv_pipe_config): mode 0 never / 1 policy / 2 whenever possible."""
     lib().call('cy_conv_pipe_config', int(mode), int(cap), int(bn), int(variant), int(bm_eff))

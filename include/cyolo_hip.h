@@ -143,6 +143,10 @@ int cy_conv_dgrad_bn_sums(const void* g, int N, int GH, int GW, int GC, int ldg,
  * Cin a multiple of 64, 16-bit output with OC and ldo multiples of 8, enough pixel tiles to fill the chip); every
  * other launch runs on conv_igemm.hip's 4-wave kernels.  Diagnostics for tests and profiles. */
 int64_t cy_pipe_launches(void);
+/* Number of launches since load that ran on the direct small-Cin 3x3 kernel (csrc/conv_direct.hip: 16-bit forward convs
+ * 3(8) -> 32 stride 1 and 32 -> 64 stride 1 / 2 with pad 1, BN statistics into shared bins or the eval-mode epilogue;
+ * CY_CONV_TILE(1) or CY_CONV_DIRECT=0 in the environment keep a call on the implicit-GEMM kernels). */
+int64_t cy_direct_launches(void);
 /* Test / tool switch, not used on the step path.  mode 0: never use the pipelined kernel, 1: default (hints and the
  * eval-mode epilogue select it), 2: every launch that qualifies; cap x bn (0 x 0 = policy) forces a tile capacity out of
  * {384,256,192,128} x 128 / {384,256,128} x 64 with bm_eff (0 = cap) pixels of it used; variant 0: shipped (3-stage ring,

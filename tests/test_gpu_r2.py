@@ -432,3 +432,54 @@ def test_two_stage_deterministic_folds():
         got.append(gb)
     torch.testing.assert_close(got[0], ref, rtol=1e-5, atol=1e-5)
     assert torch.equal(got[0], got[1])
+
+
+# (N, Cin, H, W, Cout, stride): the three shapes conv_direct.hip serves, at sizes that leave partial tiles on every edge
+DIRECT = [(2, 3, 70, 90, 32, 1), (3, 32, 45, 77, 64, 1), (2, 32, 61, 83, 64, 2), (1, 32, 64, 64, 64, 2), (1, 3, 608, 608, 32, 1)]
+
+
+@pytest.mark.parametrize('dt', [CY_F16, CY_BF16])
+@pytest.mark.parametrize('case', DIRECT)
+def test_direct_small_cin_conv(dt, case):
+    """conv_direct.hip (3 -> 32, 32 -> 64 s1 / s2 forward) against float64 torch and against the 4-wave implicit-GEMM kernel
+    (CY_CONV_TILE(1)): training launch (raw output + BN statistics) and eval launch (affine + activation + shortcut)."""
+    N, Ci, H, W, Co, st = case
+    tol = dict(rtol=1.6e-2, atol=1.6e-2) if dt == CY_BF16 else dict(rtol=2e-3, atol=2e-3)
+    rnd = (lambda t: t.bfloat16().float()) if dt == CY_BF16 else (lambda t: t.half().float())
+    g = torch.Generator().manual_seed(Ci + H + W)
+    x = rnd(torch.randn(N, Ci, H, W, generator=g))
+    w = rnd(torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9))
+    ref = F.conv2d(x.double(), w.double(), None, st, 1)
+    OH, OW = ref.shape[2], ref.shape[3]
+    cpad = (Ci + 7) // 8 * 8
+    xv = View.from_nchw(x.to(DEV), dt, cpad=cpad)
+    wf, _ = ops.pack_weights(w.to(DEV), Co, cpad, dt)
+    rows = ops.conv_stats_rows(N * OH * OW, Co)
+    outs, sts = [], []
+    for hint in (0, 1):                                   # 0: library default (the direct kernel), 1: the 4-wave kernel
+        out = View.alloc(N, OH, OW, Co, dt, zero=True)
+        stats = torch.zeros(rows, 2, Co, device=DEV)
+        n0 = ops.direct_launches()
+        ops.conv_igemm(xv, wf, Co, out, 3, st, 1, flags=ops.CONV_STATS, stats=stats, tile=hint)
+        assert ops.direct_launches() - n0 == (1 if hint == 0 else 0)
+        outs.append(out.to_nchw().cpu())
+        sts.append(stats.sum(0).cpu().double())
+    torch.testing.assert_close(outs[0], ref.float(), **tol)
+    assert torch.equal(outs[0], outs[1]) or float((outs[0] - outs[1]).abs().max()) <= tol['atol']
+    torch.testing.assert_close(sts[0][0], ref.sum((0, 2, 3)), rtol=1e-3, atol=N * OH * OW * 1e-5)
+    torch.testing.assert_close(sts[0][1], (ref ** 2).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    # eval epilogue: act(conv * scale + shift) + res
+    scale, shift = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2
+    res = rnd(torch.randn(N, Co, OH, OW, generator=g))
+    resv = View.from_nchw(res.to(DEV), dt)
+    for act in ('mish', 'leaky'):
+        z = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        want = (z * torch.tanh(F.softplus(z)) if act == 'mish' else F.leaky_relu(z, 0.1)) + res.double()
+        got = []
+        for hint in (0, 1):
+            out = View.alloc(N, OH, OW, Co, dt, zero=True)
+            ops.conv_bn_act_eval(xv, wf, Co, out, 3, st, 1, scale.to(DEV), shift.to(DEV), ops.ACT[act], resv, tile=hint)
+            got.append(out.to_nchw().cpu())
+        etol = dict(rtol=2.5e-2, atol=2.5e-2) if dt == CY_BF16 else dict(rtol=4e-3, atol=4e-3)
+        torch.testing.assert_close(got[0], want.float(), **etol)
+        torch.testing.assert_close(got[0], got[1], **etol)
