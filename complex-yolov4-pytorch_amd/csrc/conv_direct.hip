@@ -250,6 +250,221 @@ int direct_launch(const IgemmParams& p, hipStream_t s) {
     return 0;
 }
 
+// ---- 1x1 / stride 1 (forward, eval, and the 1x1 dgrad, which is the same GEMM on the dgrad weight matrix) ----------------
+// On the 304 / 152 grids these are streams of 100-750 MB through a K of 64 or 128: one K step per tile on the implicit-GEMM
+// kernels, i.e. all prologue and epilogue.  Same structure as above without the halo: persistent blocks over tiles of TP
+// consecutive pixels, weights [Cout][Cin] resident in LDS, the tile's rows [pixel][Cin] copied once (16-byte chunk index XOR
+// the pixel index: conflict-free B reads), the next tile prefetched into registers, epilogue in 64-channel passes.
+template <typename T, int CIN, int COUT, int SPW>
+struct PwCfg {
+    static constexpr int NWAVE = 4, NT = 256, TP = NWAVE * SPW * 32;
+    static constexpr int PXB = CIN * 2, CPP = CIN / 8, KS = CIN / 16, NCB = COUT / 32;
+    static constexpr int WROW = CIN * 2 + 16;
+    static constexpr int W_BYTES = COUT * WROW;
+    static constexpr int PATCH_BYTES = TP * PXB;
+    static constexpr int CW = COUT < 64 ? COUT : 64;                        // channels per epilogue pass
+    static constexpr int SROW = CW * 4 + 16;
+    static constexpr int ST_BYTES = NWAVE * 32 * SROW;
+    static constexpr int P_BYTES = PATCH_BYTES > ST_BYTES ? PATCH_BYTES : ST_BYTES;
+    static constexpr int RED_BYTES = NWAVE * 2 * COUT * 4 + 2 * COUT * 4;
+    static constexpr int SMEM = W_BYTES + P_BYTES + RED_BYTES;
+    static constexpr int NCH = TP * CPP, NIT = NCH / NT;
+    static_assert(CIN % 16 == 0 && COUT % 32 == 0 && NCH % NT == 0 && SMEM <= 80 * 1024, "tile layout");
+};
+
+template <typename T, int CIN, int COUT, int SPW>
+__global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) {
+    typedef PwCfg<T, CIN, COUT, SPW> C;
+    typedef typename Mma32<T>::frag frag;
+    typedef T tx8 __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;
+    unsigned char* patch = smem + C::W_BYTES;
+    unsigned char* stage = patch;
+    float* red = reinterpret_cast<float*>(patch + C::P_BYTES);
+    float* asc = red + C::NWAVE * 2 * COUT;
+    float* ash = asc + COUT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    {
+        constexpr int CPRW = CIN * 2 / 16;
+        for (int idx = tid; idx < COUT * CPRW; idx += C::NT) {
+            const int row = idx / CPRW, ch = idx - row * CPRW;
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (row < p.wrows) v = *reinterpret_cast<const u32x4*>(p.w + (size_t)row * (CIN * 2) + ch * 16);
+            *reinterpret_cast<u32x4*>(wl + row * C::WROW + ch * 16) = v;
+        }
+    }
+    const bool stats = (p.flags & CY_CONV_STATS) != 0, affine = (p.flags & CY_CONV_AFFINE_ACT) != 0;
+    const bool accum = (p.flags & CY_CONV_ACCUM) != 0;
+    if (affine)
+        for (int c = tid; c < COUT; c += C::NT) { asc[c] = p.aff_scale[min(c, p.OC - 1)]; ash[c] = p.aff_shift[min(c, p.OC - 1)]; }
+    constexpr int NSB = (COUT + 63) / 64;
+    float ssum[NSB], qsum[NSB];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) { ssum[sb] = 0.f; qsum[sb] = 0.f; }
+    const long M = p.M;
+    const int ntiles = (int)((M + C::TP - 1) / C::TP);
+    const size_t pixg = (size_t)p.ldg * 2, pixo = (size_t)p.ldo * 2;
+
+    u32x4 pre[C::NIT];
+    auto issue = [&](int tile) {
+        const long m0 = (long)tile * C::TP;
+#pragma unroll
+        for (int it = 0; it < C::NIT; ++it) {
+            const int idx = it * C::NT + tid, px = idx / C::CPP, c = idx - px * C::CPP;
+            pre[it] = u32x4{0u, 0u, 0u, 0u};
+            if (m0 + px < M) pre[it] = *reinterpret_cast<const u32x4*>(p.g + (size_t)(m0 + px) * pixg + c * 16);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long m0 = (long)tile * C::TP;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < C::NIT; ++it) {
+            const int idx = it * C::NT + tid, px = idx / C::CPP, c = idx - px * C::CPP;
+            *reinterpret_cast<u32x4*>(patch + px * C::PXB + ((c ^ (px & (C::CPP - 1))) << 4)) = pre[it];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        f32x16 acc[SPW][C::NCB];
+#pragma unroll
+        for (int s = 0; s < SPW; ++s)
+#pragma unroll
+            for (int cb = 0; cb < C::NCB; ++cb)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[s][cb][t] = 0.f;
+#pragma unroll
+        for (int j = 0; j < C::KS; ++j) {
+            const int cch = 2 * j + half;
+            frag a[C::NCB];
+#pragma unroll
+            for (int cb = 0; cb < C::NCB; ++cb)
+                a[cb] = *reinterpret_cast<const frag*>(wl + (cb * 32 + l31) * C::WROW + j * 32 + half * 16);
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                const int px = (wave * SPW + s) * 32 + l31;
+                const frag b = *reinterpret_cast<const frag*>(patch + px * C::PXB + ((cch ^ (px & (C::CPP - 1))) << 4));
+#pragma unroll
+                for (int cb = 0; cb < C::NCB; ++cb) acc[s][cb] = Mma32<T>::mma(a[cb], b, acc[s][cb]);
+            }
+        }
+        __syncthreads();
+        unsigned char* wst = stage + wave * (32 * C::SROW);
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            const long ms = m0 + (wave * SPW + s) * 32;
+            const int nvalid = (int)(M - ms < 32 ? (M - ms > 0 ? M - ms : 0) : 32);
+#pragma unroll
+            for (int pass = 0; pass < COUT / C::CW; ++pass) {      // 64 channels (two 32-channel MFMA blocks) at a time
+#pragma unroll
+                for (int cbl = 0; cbl < C::CW / 32; ++cbl) {
+                    const int cb = pass * (C::CW / 32) + cbl;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[s][cb][4 * g + r];
+                            if (affine) {
+                                const int co = cb * 32 + 8 * g + 4 * half + r;
+                                const float z = v * asc[co] + ash[co];
+                                const float zm = mish_f<true>(z), zl = z > 0.f ? z : 0.1f * z;
+                                v = p.act == CY_ACT_MISH ? zm : (p.act == CY_ACT_LEAKY ? zl : z);
+                            }
+                            h[r] = v;
+                        }
+                        *reinterpret_cast<f32x4*>(wst + l31 * C::SROW + (cbl * 32 + 8 * g + 4 * half) * 4) = h;
+                    }
+                }
+                if (stats && lane < C::CW) {
+                    float sv = 0.f, qv = 0.f;
+                    for (int r = 0; r < nvalid; ++r) {
+                        const float v = *reinterpret_cast<const float*>(wst + r * C::SROW + lane * 4);
+                        sv += v;
+                        qv += v * v;
+                    }
+                    // lane c of pass `pass` owns channel pass*CW + c: NSB accumulators indexed by the pass (CW = 64) or 0
+                    ssum[C::CW == 64 ? pass : 0] += sv;
+                    qsum[C::CW == 64 ? pass : 0] += qv;
+                }
+                constexpr int CPO = C::CW / 8;
+#pragma unroll
+                for (int it = 0; it < 32 * CPO / 64; ++it) {
+                    const int idx = it * 64 + lane, px = idx / CPO, ch = idx - px * CPO;
+                    const int co = pass * C::CW + ch * 8;
+                    if (px >= nvalid || co >= p.OC) continue;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(wst + px * C::SROW + ch * 32);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(wst + px * C::SROW + ch * 32 + 16);
+                    float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const size_t opix = (size_t)(ms + px);
+                    T* dst = reinterpret_cast<T*>(p.o + opix * pixo) + co;
+                    if (affine && p.res) {
+                        const tx8 rv = *reinterpret_cast<const tx8*>(reinterpret_cast<const T*>(p.res) + opix * p.ldres + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += (float)rv[e];
+                    }
+                    if (accum) {
+                        const tx8 ov = *reinterpret_cast<const tx8*>(dst);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += (float)ov[e];
+                    }
+                    tx8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (T)f[e];
+                    *reinterpret_cast<tx8*>(dst) = v;
+                }
+            }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+            const int c = sb * 64 + lane;
+            if (lane < C::CW && c < COUT) {
+                red[(wave * 2 + 0) * COUT + c] = ssum[sb];
+                red[(wave * 2 + 1) * COUT + c] = qsum[sb];
+            }
+        }
+        __syncthreads();
+        float* srow = p.stats + (size_t)(blockIdx.x & (CY_STAT_BINS - 1)) * 2 * p.OC;
+        for (int c = tid; c < 2 * COUT; c += C::NT) {
+            const int mom = c / COUT, co = c - mom * COUT;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::NWAVE; ++w) t += red[(w * 2 + mom) * COUT + co];
+            if (co < p.OC) atomicAdd(srow + mom * p.OC + co, t);
+        }
+    }
+}
+
+template <typename T, int CIN, int COUT, int SPW>
+int pw_launch(const IgemmParams& p, hipStream_t s) {
+    typedef PwCfg<T, CIN, COUT, SPW> C;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct1x1_kernel<T, CIN, COUT, SPW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        attr_done = true;
+    }
+    const long tiles = (p.M + C::TP - 1) / C::TP;
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
+    hipLaunchKernelGGL((direct1x1_kernel<T, CIN, COUT, SPW>), dim3(grid), dim3(256), C::SMEM, s, p);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int pw_dispatch(const IgemmParams& p, hipStream_t s, int* used) {
+    *used = 1;
+#define CY_PW(CI, CO, SP) if (p.GC == CI && p.OC == CO) return pw_launch<T, CI, CO, SP>(p, s);
+    CY_PW(64, 64, 2) CY_PW(128, 64, 1) CY_PW(64, 128, 1) CY_PW(64, 32, 2) CY_PW(32, 64, 2)
+#undef CY_PW
+    *used = 0;
+    return 0;
+}
+
 template <typename T>
 int direct_dispatch(const IgemmParams& p, hipStream_t s, int* used) {
     *used = 1;
@@ -278,10 +493,19 @@ int cy_direct_try(const cyk::IgemmParams& p, int dtype, hipStream_t s, int* used
     }
     const int hint = (p.flags >> CY_CONV_TILE_SHIFT) & 15;
     if (!g_direct_mode || hint == 1 || (dtype != CY_F16 && dtype != CY_BF16)) return 0;
-    if (p.ks != 3 || p.pad != 1 || p.transposed || p.stat_det) return 0;
-    if (p.flags & (CY_CONV_BIAS_F32OUT | CY_CONV_ACCUM | CY_CONV_BNBWD_SUMS)) return 0;
+    if (p.stat_det || (p.flags & (CY_CONV_BIAS_F32OUT | CY_CONV_BNBWD_SUMS))) return 0;
     if (p.ldg % 8 || p.ldo % 8 || ((uintptr_t)p.g & 15) || ((uintptr_t)p.o & 15) || ((uintptr_t)p.w & 15)) return 0;
     if (p.res && (p.ldres % 8 || ((uintptr_t)p.res & 15))) return 0;
+    if (p.ks == 1 && p.stride == 1 && p.pad == 0) {
+        // 1x1 streams: worth it where the launch is long enough to fill the persistent grid several times over (the 152 / 304
+        // grids at batch 16); smaller launches stay with the implicit-GEMM kernels unless the caller asks (hint 10)
+        if (p.M < 256L * 1024 && hint != 10) return 0;
+        if (p.OH != p.GH || p.OW != p.GW) return 0;
+        const int rc = dtype == CY_F16 ? pw_dispatch<f16>(p, s, used) : pw_dispatch<bf16>(p, s, used);
+        if (rc == 0 && *used) ++g_direct_launches;
+        return rc;
+    }
+    if (p.ks != 3 || p.pad != 1 || p.transposed || (p.flags & CY_CONV_ACCUM)) return 0;
     if (p.OH != (p.GH + 2 - 3) / p.stride + 1 || p.OW != (p.GW + 2 - 3) / p.stride + 1) return 0;
     const int rc = dtype == CY_F16 ? direct_dispatch<f16>(p, s, used) : direct_dispatch<bf16>(p, s, used);
     if (rc == 0 && *used) ++g_direct_launches;

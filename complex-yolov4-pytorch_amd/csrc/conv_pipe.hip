@@ -607,7 +607,8 @@ int cy_pipe_try(const cyk::IgemmParams& p0, int dtype, hipStream_t s, int* used)
         const char* e = getenv("CY_CONV_PIPE");
         g_pipe_mode = e ? atoi(e) : 1;
     }
-    const int hint = (p0.flags >> CY_CONV_TILE_SHIFT) & 15;
+    int hint = (p0.flags >> CY_CONV_TILE_SHIFT) & 15;
+    if (hint > 9) hint = 0;          // 10: the direct kernels (conv_direct.hip); a call they do not take is an ordinary one here
     if (g_pipe_mode == 0 || hint == 1 || (dtype != CY_F16 && dtype != CY_BF16)) return 0;
     if (g_pipe_mode == 1 && hint == 0 && !(p0.flags & (CY_CONV_AFFINE_ACT | CY_CONV_BNBWD_SUMS))) return 0;
     if ((p0.flags & CY_CONV_BNBWD_SUMS) && (p0.ldres % 8 || ((uintptr_t)p0.res & 15))) return 0;

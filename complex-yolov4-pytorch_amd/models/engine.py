@@ -314,10 +314,15 @@ class Engine:
         ops.slice_add(self.view(rec['a']), self.view(rec['b']), self.view(rec['out']))
 
     def _f_yolo(self, rec, targets, use_giou, img_size):
-        if self.side is not None and targets is not None and not self._in_side_head and os.environ.get('CY_HEADS_SIDE', '1') != '0':
-            # training: the decode + loss kernels of a head are a dozen two-wave launches (one lane per target in the
-            # polygon clip), ~0.15 ms of latency that nothing downstream needs before the loss is read -- they run on the
-            # side stream beside the trunk convs that follow the head (forward() joins the streams at the end)
+        if self.side is not None and targets is not None and not self._in_side_head and os.environ.get('CY_HEADS_SIDE', '0') == '1':
+            # OPT-IN (CY_HEADS_SIDE=1), off by default.  The decode + loss kernels of a head are a dozen two-wave launches
+            # (one lane per target in the polygon clip), ~0.15 ms of latency that nothing downstream needs before the loss
+            # is read; on the side stream beside the trunk convs that follow the head they are worth +1 % of the step.
+            # But cy_yolo_loss is NOT reproducible while other kernels run beside it: tools/head_race_probe.py shows 1 in
+            # ~300 launches with different d(logits) (1.8e-2) on identical inputs when conv kernels are in flight on another
+            # queue, none otherwise -- assign_kernel / pairs_kernel are the only kernels of the step that use scratch memory
+            # (368 / 880 bytes per lane of dynamically indexed polygon arrays).  Until those arrays live in LDS the heads
+            # stay on the main stream, where nothing runs beside them.
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side.wait_event(ev)
@@ -452,6 +457,8 @@ class Engine:
         hints = [] if pipe_only else [1]
         if ks == 3 and cin in (8, 32) and not pipe_only:
             hints.append(0)       # forward 3 -> 32 / 32 -> 64: the library default is the direct small-Cin kernel (conv_direct.hip)
+        if ks == 1 and (cin, cout) in ((64, 64), (128, 64), (64, 128), (64, 32), (32, 64)) and not pipe_only:
+            hints.append(10)      # 1x1 streams: the direct kernel, also below the library's own size threshold
         if cin % 64 == 0 and cout % 8 == 0:
             hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h in (3, 8) and cout <= 64)]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -529,7 +536,8 @@ class Engine:
                 # (timing an accumulating launch adds garbage into a gradient buffer that the real backward has not written
                 # yet at this point: every first writer of the step stores)
                 hint, t_plain = self._time_hints_t(key, lambda h: ops.conv_igemm(
-                    dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], flags=flags, tile=h), dy.C, ref.C)
+                    dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], flags=flags, tile=h), dy.C, ref.C,
+                    ks=(1 if rec['ks'] == 1 and rec['stride'] == 1 else 0))
                 self._dgrad_tile[(rec['idx'], ref.c0)] = hint
                 L = b.get('dx_sums', {}).get(ri) if can_fuse else None
                 if L is None:

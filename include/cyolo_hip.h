@@ -111,6 +111,8 @@ int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dt
  *                               every step times the candidates once): 0 library default, 1 the 4-wave kernels, 2-5 the
  *                               8-wave pipelined kernel with a 128 / 192 / 256 / 384-pixel tile, 6 with its own tile policy,
  *                               7-9 its loader / compute split (4 + 8 waves) with a 128 / 192 / 256-pixel tile
+ *                               10 the direct streaming kernels of conv_direct.hip also where the library default would not
+ *                               pick them (1x1 launches of fewer than 256 k pixels)
  *                               (the hint is ignored where that kernel does not apply: f32, first layers, fp32 output)
  * Returns the number of stats rows written through *stats_rows when non-NULL. */
 int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out, int OH,
@@ -143,9 +145,11 @@ int cy_conv_dgrad_bn_sums(const void* g, int N, int GH, int GW, int GC, int ldg,
  * Cin a multiple of 64, 16-bit output with OC and ldo multiples of 8, enough pixel tiles to fill the chip); every
  * other launch runs on conv_igemm.hip's 4-wave kernels.  Diagnostics for tests and profiles. */
 int64_t cy_pipe_launches(void);
-/* Number of launches since load that ran on the direct small-Cin 3x3 kernel (csrc/conv_direct.hip: 16-bit forward convs
- * 3(8) -> 32 stride 1 and 32 -> 64 stride 1 / 2 with pad 1, BN statistics into shared bins or the eval-mode epilogue;
- * CY_CONV_TILE(1) or CY_CONV_DIRECT=0 in the environment keep a call on the implicit-GEMM kernels). */
+/* Number of launches since load that ran on the direct streaming kernels (csrc/conv_direct.hip, 16-bit types): the 3x3
+ * forward convs 3(8) -> 32 stride 1 and 32 -> 64 stride 1 / 2 with pad 1, and 1x1 stride-1 convs (forward, eval, dgrad with
+ * or without fan-in accumulation) of 64->64, 128->64, 64->128, 64->32, 32->64 channels on launches of >= 256 k pixels;
+ * BN statistics into shared bins or the eval-mode epilogue.  CY_CONV_TILE(1) or CY_CONV_DIRECT=0 in the environment keep
+ * a call on the implicit-GEMM kernels. */
 int64_t cy_direct_launches(void);
 /* Test / tool switch, not used on the step path.  mode 0: never use the pipelined kernel, 1: default (hints and the
  * eval-mode epilogue select it), 2: every launch that qualifies; cap x bn (0 x 0 = policy) forces a tile capacity out of

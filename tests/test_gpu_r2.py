@@ -483,3 +483,72 @@ def test_direct_small_cin_conv(dt, case):
         etol = dict(rtol=2.5e-2, atol=2.5e-2) if dt == CY_BF16 else dict(rtol=4e-3, atol=4e-3)
         torch.testing.assert_close(got[0], want.float(), **etol)
         torch.testing.assert_close(got[0], got[1], **etol)
+
+
+# (Cin, Cout) instantiations of the 1x1 streaming kernel; M is ragged (not a multiple of the 128 / 256-pixel tile)
+PW = [(64, 64), (128, 64), (64, 128), (64, 32), (32, 64)]
+
+
+@pytest.mark.parametrize('dt', [CY_F16, CY_BF16])
+@pytest.mark.parametrize('ci,co', PW)
+def test_direct_1x1_stream_conv(dt, ci, co):
+    """conv_direct.hip's 1x1 kernel (CY_CONV_TILE(10)) against float64 torch and the 4-wave kernel: forward with BN statistics,
+    eval epilogue with shortcut, and the 1x1 dgrad (store and fan-in accumulate), on channel-slice views (ld > C)."""
+    N, H, W = 3, 37, 53
+    tol = dict(rtol=1.6e-2, atol=1.6e-2) if dt == CY_BF16 else dict(rtol=2e-3, atol=2e-3)
+    rnd = (lambda t: t.bfloat16().float()) if dt == CY_BF16 else (lambda t: t.half().float())
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    x = rnd(torch.randn(N, ci, H, W, generator=g))
+    w = rnd(torch.randn(co, ci, 1, 1, generator=g) / math.sqrt(ci))
+    ref = F.conv2d(x.double(), w.double())
+    xv = View.from_nchw(x.to(DEV), dt, ld=ci + 64)            # a slice of a wider storage
+    wf, wd = ops.pack_weights(w.to(DEV), co, ci, dt)
+    M = N * H * W
+    rows = ops.conv_stats_rows(M, co)
+    res = {}
+    for hint in (10, 1):
+        out = View.from_nchw(torch.zeros(N, co, H, W, device=DEV), dt, ld=co + 32)
+        stats = torch.zeros(rows, 2, co, device=DEV)
+        n0 = ops.direct_launches()
+        ops.conv_igemm(xv, wf, co, out, 1, 1, 0, flags=ops.CONV_STATS, stats=stats, tile=hint)
+        assert ops.direct_launches() - n0 == (1 if hint == 10 else 0)
+        res[hint] = (out.to_nchw().cpu(), stats.sum(0).cpu().double())
+    torch.testing.assert_close(res[10][0], ref.float(), **tol)
+    torch.testing.assert_close(res[10][0], res[1][0], **tol)
+    torch.testing.assert_close(res[10][1][0], ref.sum((0, 2, 3)), rtol=1e-3, atol=M * 1e-5)
+    torch.testing.assert_close(res[10][1][1], (ref ** 2).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    # eval epilogue
+    scale, shift = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.2
+    r = rnd(torch.randn(N, co, H, W, generator=g))
+    rv = View.from_nchw(r.to(DEV), dt)
+    z = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    want = z * torch.tanh(F.softplus(z)) + r.double()
+    out = View.alloc(N, H, W, co, dt, zero=True)
+    ops.conv_bn_act_eval(xv, wf, co, out, 1, 1, 0, scale.to(DEV), shift.to(DEV), ops.ACT['mish'], rv, tile=10)
+    etol = dict(rtol=2.5e-2, atol=2.5e-2) if dt == CY_BF16 else dict(rtol=4e-3, atol=4e-3)
+    torch.testing.assert_close(out.to_nchw().cpu(), want.float(), **etol)
+    # dgrad of the same layer: dX[p][ci] = sum_co dY[p][co] W[co][ci]; its (Cin, Cout) roles are swapped
+    if (co, ci) in PW:
+        dy = rnd(torch.randn(N, co, H, W, generator=g))
+        dyv = View.from_nchw(dy.to(DEV), dt)
+        gref = torch.nn.grad.conv2d_input((N, ci, H, W), w.double(), dy.double())
+        base = rnd(torch.randn(N, ci, H, W, generator=g))
+        for acc in (False, True):
+            dx = View.from_nchw(base.to(DEV), dt)
+            n0 = ops.direct_launches()
+            ops.conv_igemm(dyv, wd, ci, dx, 1, 1, 0, flags=ops.CONV_TRANSPOSED | (ops.CONV_ACCUM if acc else 0), tile=10)
+            assert ops.direct_launches() - n0 == 1
+            wantg = gref + (base.double() if acc else 0)
+            torch.testing.assert_close(dx.to_nchw().cpu(), wantg.float(), **etol)
+
+
+def test_direct_1x1_default_threshold():
+    """Without a hint the 1x1 stream kernel takes launches of >= 256 k pixels only."""
+    for H, expect in ((152, 1), (76, 0)):
+        x = View.alloc(16, H, H, 64, CY_F16, zero=True)
+        out = View.alloc(16, H, H, 64, CY_F16)
+        wf = torch.zeros(64, 64, dtype=torch.float16, device=DEV)
+        stats = torch.zeros(ops.conv_stats_rows(16 * H * H, 64) * 2 * 64, device=DEV)
+        n0 = ops.direct_launches()
+        ops.conv_igemm(x, wf, 64, out, 1, 1, 0, flags=ops.CONV_STATS, stats=stats)
+        assert ops.direct_launches() - n0 == expect

@@ -15,7 +15,7 @@ torch.manual_seed(0)
 model = Darknet(cfg, use_giou_loss=True, dtype=dtype, deterministic=True).cuda().train()
 x, tg = syn.bev_images(B, 608, seed=5).cuda(), syn.targets(B, 6, 608, seed=5).cuda()
 snaps = []
-for it in range(3):
+for it in range(int(os.environ.get("DET_RUNS", "3"))):
     model.zero_grad(set_to_none=True)
     loss, out = model(x, tg)
     eng = next(iter(model._engines.values()))
@@ -27,7 +27,7 @@ for it in range(3):
     snaps.append((float(loss), fwd, bwd, model.flat_grad.clone(), {k: v.clone() for k, v in eng.bnvec.items()}))
     print('run', it, 'loss %.6f' % float(loss), 'tiles fwd', sorted(set(eng._fwd_tile.values())), 'dgrad', sorted(set(eng._dgrad_tile.values())))
 plan = eng.plan
-for a, b in ((0, 1), (1, 2)):
+for a, b in [(i, i + 1) for i in range(len(snaps) - 1)]:
     print('--- run %d vs run %d' % (a, b))
     first = None
     for rec in plan.fwd:
