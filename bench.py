@@ -375,7 +375,7 @@ def main():
             peak = MFMA_PEAK_TFLOPS[a.dtype]
             tr = pmc_traffic('igemm', a)
             roofline = dict(bound='mfma', kernel='implicit-GEMM conv kernels (forward + dgrad launches: igemm_fast_kernel / igemm_kernel '
-                                                 '4-wave tiles and igemm_pipe_kernel 8-wave tiles, chosen per layer; dgrad launches that also accumulate BatchNorm-backward sums included)',
+                                                 '4-wave tiles, igemm_pipe_kernel 8-wave tiles, direct3x3 / direct1x1 streaming kernels for the small-Cin and big-grid 1x1 layers, chosen per layer; dgrad launches that also accumulate BatchNorm-backward sums included)',
                             achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
                             traffic=(tr or {}).get('bytes_per_launch'), traffic_detail=tr,
                             launches_per_step=ig['launches'] // 2, avg_launch_us=round(1e3 * ig['ms_raw'] / ig['launches'], 2),
