@@ -412,7 +412,7 @@ def main():
                       'train1024': measure_train(dev, 8, 1024, a.dtype, 5, 2)}
             if a.dtype == 'f16':
                 others['train608_bf16'] = measure_train(dev, 16, 608, 'bf16', 6, 3)
-            others['train1216_mosaic'] = measure_train(dev, 16, 1216, a.dtype, 3, 2, mosaic=True)
+            others['train1216_mosaic'] = measure_train(dev, 16, 1216, a.dtype, 4, 3, mosaic=True)
         if not a.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(2, a.size)
         imgs = world * a.batch * a.steps
