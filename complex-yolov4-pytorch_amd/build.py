@@ -11,6 +11,11 @@ LIB = os.path.join(CSRC, 'libcyolo_hip.so')
 SOURCES = ['conv_igemm.hip', 'conv_pipe.hip', 'conv_direct.hip', 'conv_wgrad.hip', 'elementwise.hip', 'yolo_head.hip', 'riou_nms.hip', 'bev.hip']
 HEADERS = ['common.hpp', 'igemm_common.hpp', 'geometry.hpp', os.path.join(INCLUDE, 'cyolo_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC, '-Wno-unused-value']
+# Per-file flags.  yolo_head.hip: the per-target kernels (assign, pairs) index small polygon arrays dynamically; with the default
+# promote-alloca budget they lived in scratch memory (368 / 880 bytes per lane) and were the only kernels of the step whose
+# results changed when another kernel ran beside them (tools/head_race_probe.py).  With this budget (and their 64-thread
+# launch bounds) every array is a register vector: ScratchSize 0.
+EXTRA_FLAGS = {'yolo_head.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=1024']}
 
 
 def _mtime(p):
@@ -26,7 +31,7 @@ def build(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _mtime(o) < max(_mtime(s), hdr_time):
-            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -149,7 +149,7 @@ __device__ inline int hull8(const float* x, const float* y, int* out) {
         while (j >= 0 && (x[ord[j]] > x[k] || (x[ord[j]] == x[k] && y[ord[j]] > y[k]))) { ord[j + 1] = ord[j]; --j; }
         ord[j + 1] = k;
     }
-    int h[18];
+    int h[16];   // lower chain <= 8 entries, the upper adds <= 7 (16 elements stay a register vector; 18 went to scratch)
     int m = 0;
     auto cross = [&](int o, int a, int b) {
         return ((double)x[a] - (double)x[o]) * ((double)y[b] - (double)y[o]) -
@@ -169,8 +169,10 @@ __device__ inline int hull8(const float* x, const float* y, int* out) {
     return m;
 }
 
-// One (prediction, target) pair.  p/t: (x, y, w, l, im, re).
-__device__ inline PairOut pair_term(const float* p, const float* t, bool giou) {
+// One (prediction, target) pair.  p/t: (x, y, w, l, im, re).  The loss variant is a template parameter so that a kernel
+// which knows it at launch carries the local arrays of ONE path only (they then fit in registers: no scratch).
+template <bool giou>
+__device__ inline PairOut pair_term_t(const float* p, const float* t) {
     PairOut o;
     float pcx[4], pcy[4], tcx[4], tcy[4];
     const float pyaw = atan2f(p[4], p[5]);
@@ -256,6 +258,10 @@ __device__ inline PairOut pair_term(const float* p, const float* t, bool giou) {
     o.g[4] = gyaw * (p[5] / r2);
     o.g[5] = gyaw * (-p[4] / r2);
     return o;
+}
+
+__device__ inline PairOut pair_term(const float* p, const float* t, bool giou) {
+    return giou ? pair_term_t<true>(p, t) : pair_term_t<false>(p, t);
 }
 
 }  // namespace geom

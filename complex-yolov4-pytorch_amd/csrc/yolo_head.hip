@@ -51,7 +51,10 @@ __global__ void decode_kernel(const float* __restrict__ logits, int B, int G, in
     }
 }
 
-__global__ void assign_kernel(const float* __restrict__ targets, int nT, int B, int G, int A, Anchors an,
+// (64-thread blocks, stated to the compiler: with the register budget of a single wave per SIMD the polygon arrays of the
+// two per-target kernels are promoted to registers.  They were the only kernels of the step with scratch memory -- 368 and
+// 880 bytes per lane -- and the ones whose results changed when another kernel ran beside them: tools/head_race_probe.py)
+__global__ void __launch_bounds__(64) assign_kernel(const float* __restrict__ targets, int nT, int B, int G, int A, Anchors an,
                               float ignore_thresh, Work w) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nT) return;
@@ -99,8 +102,9 @@ __device__ __forceinline__ void decode_box(const float* t, int gi, int gj, float
     box[5] = t[5];
 }
 
-__global__ void pairs_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT, int G, int A,
-                             int C, Anchors an, int use_giou, Work w) {
+template <bool GIOU>
+__global__ void __launch_bounds__(64) pairs_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
+                                                   int G, int A, int C, Anchors an, Work w) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nT) return;
     const int b = w.ti[k * 4];
@@ -117,7 +121,7 @@ __global__ void pairs_kernel(const float* __restrict__ logits, const float* __re
     const float* t = targets + (long)k * 8;
     const float gf = (float)G;
     tb[0] = t[2] * gf; tb[1] = t[3] * gf; tb[2] = t[4] * gf; tb[3] = t[5] * gf; tb[4] = t[6]; tb[5] = t[7];
-    const geom::PairOut o = geom::pair_term(pb, tb, use_giou != 0);
+    const geom::PairOut o = geom::pair_term_t<GIOU>(pb, tb);
     tf[0] = o.iou;
     tf[1] = o.term;
     for (int i = 0; i < 6; ++i) tf[2 + i] = o.g[i];
@@ -359,7 +363,8 @@ extern "C" int cy_yolo_loss(const float* logits, int B, int G, int A, int C, con
     const int tb = (nT + 63) / 64;
     if (nT > 0) {
         hipLaunchKernelGGL(assign_kernel, dim3(tb), dim3(64), 0, cy_s(s), targets, nT, B, G, A, an, ignore_thresh, w);
-        hipLaunchKernelGGL(pairs_kernel, dim3(tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, use_giou, w);
+        if (use_giou) hipLaunchKernelGGL(pairs_kernel<true>, dim3(tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, w);
+        else hipLaunchKernelGGL(pairs_kernel<false>, dim3(tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, w);
     }
     const int grid = (int)((cells + 255) / 256 > 2048 ? 2048 : (cells + 255) / 256);
     hipLaunchKernelGGL(dense_kernel, dim3(grid), dim3(256), 0, cy_s(s), logits, targets, B, G, A, C, an, sc, w, dlogits);

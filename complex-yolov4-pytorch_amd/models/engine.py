@@ -314,15 +314,15 @@ class Engine:
         ops.slice_add(self.view(rec['a']), self.view(rec['b']), self.view(rec['out']))
 
     def _f_yolo(self, rec, targets, use_giou, img_size):
-        if self.side is not None and targets is not None and not self._in_side_head and os.environ.get('CY_HEADS_SIDE', '0') == '1':
-            # OPT-IN (CY_HEADS_SIDE=1), off by default.  The decode + loss kernels of a head are a dozen two-wave launches
-            # (one lane per target in the polygon clip), ~0.15 ms of latency that nothing downstream needs before the loss
-            # is read; on the side stream beside the trunk convs that follow the head they are worth +1 % of the step.
-            # But cy_yolo_loss is NOT reproducible while other kernels run beside it: tools/head_race_probe.py shows 1 in
-            # ~300 launches with different d(logits) (1.8e-2) on identical inputs when conv kernels are in flight on another
-            # queue, none otherwise -- assign_kernel / pairs_kernel are the only kernels of the step that use scratch memory
-            # (368 / 880 bytes per lane of dynamically indexed polygon arrays).  Until those arrays live in LDS the heads
-            # stay on the main stream, where nothing runs beside them.
+        if (self.side is not None and targets is not None and not self._in_side_head and not self.det
+                and os.environ.get('CY_HEADS_SIDE', '1') != '0'):
+            # training: the decode + loss kernels of a head are a dozen two-wave launches (one lane per target in the
+            # polygon clip), ~0.15 ms of latency that nothing downstream needs before the loss is read -- they run on the
+            # side stream beside the trunk convs that follow the head (forward() joins the streams at the end): +1 %.
+            # This needs the per-target kernels to be free of scratch memory (csrc/yolo_head.hip, build.py): with their
+            # polygon arrays in scratch they returned different owners / IoUs in ~1 % of launches whenever another kernel
+            # ran beside them (tools/head_race_probe.py).  What remains under concurrency is the ORDER of the fp32 atomics
+            # of colliding targets in d(logits): the deterministic mode keeps the heads on the main stream.
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side.wait_event(ev)
