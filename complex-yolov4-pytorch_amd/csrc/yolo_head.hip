@@ -230,18 +230,29 @@ __global__ void giou_grad_kernel(const float* __restrict__ logits, int nT, int G
     const int b = w.ti[k * 4];
     if (b < 0) return;
     const int a = w.ti[k * 4 + 1], gj = w.ti[k * 4 + 2], gi = w.ti[k * 4 + 3];
+    // Targets that share a (cell, anchor) add into the same six logits.  Instead of fp32 atomics (whose order, and with it
+    // the last bits of d(logits), depended on what else ran on the GPU) the FIRST target of a cell sums the contributions of
+    // all its targets in index order and is the only writer: nT is ~100, the scan is free.
+    for (int j = 0; j < k; ++j)
+        if (w.ti[j * 4] == b && w.ti[j * 4 + 1] == a && w.ti[j * 4 + 2] == gj && w.ti[j * 4 + 3] == gi) return;
     const int NCH = 7 + C;
     const long base = ((long)(b * G + gj) * G + gi) * (A * NCH) + a * NCH;
     const float* t = logits + base;
-    const float* g = w.tf + (long)k * 8 + 2;
     const float sx = sigmoidf_(t[0]), sy = sigmoidf_(t[1]);
     const float e2 = expf(t[2]), e3 = expf(t[3]);
-    atomicAdd(dlogits + base + 0, coef * g[0] * sx * (1.f - sx));
-    atomicAdd(dlogits + base + 1, coef * g[1] * sy * (1.f - sy));
-    atomicAdd(dlogits + base + 2, e2 <= 1e3f ? coef * g[2] * e2 * an.w[a] : 0.f);
-    atomicAdd(dlogits + base + 3, e3 <= 1e3f ? coef * g[3] * e3 * an.h[a] : 0.f);
-    atomicAdd(dlogits + base + 4, coef * g[4]);
-    atomicAdd(dlogits + base + 5, coef * g[5]);
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = k; j < nT; ++j) {
+        if (!(w.ti[j * 4] == b && w.ti[j * 4 + 1] == a && w.ti[j * 4 + 2] == gj && w.ti[j * 4 + 3] == gi)) continue;
+        const float* g = w.tf + (long)j * 8 + 2;
+        s[0] += coef * g[0] * sx * (1.f - sx);
+        s[1] += coef * g[1] * sy * (1.f - sy);
+        s[2] += e2 <= 1e3f ? coef * g[2] * e2 * an.w[a] : 0.f;
+        s[3] += e3 <= 1e3f ? coef * g[3] * e3 * an.h[a] : 0.f;
+        s[4] += coef * g[4];
+        s[5] += coef * g[5];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dlogits[base + i] += s[i];
 }
 
 struct LossScales {

@@ -314,15 +314,15 @@ class Engine:
         ops.slice_add(self.view(rec['a']), self.view(rec['b']), self.view(rec['out']))
 
     def _f_yolo(self, rec, targets, use_giou, img_size):
-        if (self.side is not None and targets is not None and not self._in_side_head and not self.det
+        if (self.side is not None and targets is not None and not self._in_side_head
                 and os.environ.get('CY_HEADS_SIDE', '1') != '0'):
             # training: the decode + loss kernels of a head are a dozen two-wave launches (one lane per target in the
             # polygon clip), ~0.15 ms of latency that nothing downstream needs before the loss is read -- they run on the
             # side stream beside the trunk convs that follow the head (forward() joins the streams at the end): +1 %.
             # This needs the per-target kernels to be free of scratch memory (csrc/yolo_head.hip, build.py): with their
             # polygon arrays in scratch they returned different owners / IoUs in ~1 % of launches whenever another kernel
-            # ran beside them (tools/head_race_probe.py).  What remains under concurrency is the ORDER of the fp32 atomics
-            # of colliding targets in d(logits): the deterministic mode keeps the heads on the main stream.
+            # ran beside them (tools/head_race_probe.py); and the GIoU gradient of targets sharing a cell has one writer
+            # summing in index order instead of fp32 atomics.  cy_yolo_loss is bit-reproducible whatever runs beside it.
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side.wait_event(ev)
