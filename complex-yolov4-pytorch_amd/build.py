@@ -15,7 +15,52 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, 
 # promote-alloca budget they lived in scratch memory (368 / 880 bytes per lane) and were the only kernels of the step whose
 # results changed when another kernel ran beside them (tools/head_race_probe.py).  With this budget (and their 64-thread
 # launch bounds) every array is a register vector: ScratchSize 0.
-EXTRA_FLAGS = {'yolo_head.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=1024']}
+EXTRA_FLAGS = {'yolo_head.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=1024', '-Rpass-analysis=kernel-resource-usage']}
+# kernels that must come out of the compiler without a private segment (checked on every compile of their file, see
+# check_scratch): a different hipcc or an edit of geometry.hpp can bring the spill back silently
+NO_SCRATCH = {'yolo_head.hip': ('assign_kernel', 'pairs_kernel', 'giou_grad_kernel')}
+RESOURCES = os.path.join(CSRC, 'kernel_resources.json')
+
+
+def parse_resources(text):
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {'scratch': bytes/lane, 'vgprs': n, 'sgprs': n}}."""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r'remark: Function Name: (\S+)', line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for key, pat in (('scratch', r'ScratchSize \[bytes/lane\]: (\d+)'), ('vgprs', r' VGPRs: (\d+)'), ('sgprs', r'TotalSGPRs: (\d+)')):
+            m = re.search(pat, line)
+            if m:
+                cur[key] = int(m.group(1))
+    return out
+
+
+def check_scratch(src, text):
+    """Raise when a kernel named in NO_SCRATCH[src] was compiled with a private segment; records every kernel's figures."""
+    import json
+    res = parse_resources(text)
+    try:
+        with open(RESOURCES) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        doc = {}
+    doc[src] = res
+    with open(RESOURCES, 'w') as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    wanted = NO_SCRATCH.get(src, ())
+    seen = {w: [k for k in res if w in k] for w in wanted}
+    missing = [w for w, ks in seen.items() if not ks]
+    if missing:
+        raise RuntimeError('%s: no resource-usage remark for %s (compiler output format changed?)' % (src, missing))
+    bad = {k: res[k].get('scratch') for ks in seen.values() for k in ks if res[k].get('scratch', -1) != 0}
+    if bad:
+        raise RuntimeError('%s: per-target kernels must have ScratchSize 0 (side-stream precondition, see yolo_head.hip): %s' % (src, bad))
+    return res
 
 
 def _mtime(p):
@@ -40,6 +85,12 @@ def build(force=False, verbose=False):
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError('hipcc failed on %s' % src)
+        if src in NO_SCRATCH:
+            try:
+                check_scratch(src, out.decode())
+            except RuntimeError:
+                os.remove(os.path.join(CSRC, src.replace('.hip', '.o')))     # never link an object that failed the check
+                raise
     if procs or force or _mtime(LIB) < max(_mtime(o) for o in objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

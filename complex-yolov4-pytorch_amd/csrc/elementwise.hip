@@ -729,8 +729,18 @@ struct AdamGroups {
 };
 __global__ void __launch_bounds__(256) adam_multi_kernel(const cy_adam_desc* __restrict__ desc, const int* __restrict__ blocks,
                                                         float beta1, float beta2, float eps, float bc1, float bc2,
-                                                        int zero_grad, AdamGroups grp, const int* __restrict__ skip) {
-    if (skip && *skip) return;   // a non-finite gradient was found (cy_grad_nonfinite): the step is skipped as a whole
+                                                        int zero_grad, AdamGroups grp, const int* __restrict__ skip,
+                                                        const int* __restrict__ step_in, int* __restrict__ step_out) {
+    const bool skipped = skip && *skip;   // a non-finite gradient was found (cy_grad_nonfinite): the step is skipped as a whole
+    if (step_in) {
+        // step count on the device (cy_adam_multi_dev): a skipped step does not advance it, so the bias corrections of
+        // the next step are those of t, not t + 1 -- without the host ever reading the flag
+        const int t = *step_in + 1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *step_out = skipped ? t - 1 : t;
+        bc1 = (float)(1.0 - pow((double)beta1, (double)t));
+        bc2 = (float)(1.0 - pow((double)beta2, (double)t));
+    }
+    if (skipped) return;
     const cy_adam_desc d = desc[blocks[2 * blockIdx.x]];
     const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
     const float lr = grp.lr[d.group & 7], wdecay = grp.wd[d.group & 7];
@@ -1271,7 +1281,25 @@ extern "C" int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, in
         grp.wd[i] = i < ngroups ? group_wd_host[i] : 0.f;
     }
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, beta1, beta2, eps, bias_corr1,
-                       bias_corr2, zero_grad, grp, (const int*)skip_flag);
+                       bias_corr2, zero_grad, grp, (const int*)skip_flag, (const int*)nullptr, (int*)nullptr);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cy_adam_multi_dev(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2,
+                                 float eps, const int32_t* step_in, int32_t* step_out, int zero_grad,
+                                 const float* group_lr_host, const float* group_wd_host, int ngroups,
+                                 const int32_t* skip_flag, cy_stream_t s) {
+    CY_ENTER();
+    if (!desc || !blocks || nblocks < 1 || !step_in || !step_out || step_in == step_out) return CY_ERR_ARG;
+    if (!group_lr_host || !group_wd_host || ngroups < 1 || ngroups > 8) return CY_ERR_ARG;
+    AdamGroups grp;
+    for (int i = 0; i < 8; ++i) {
+        grp.lr[i] = i < ngroups ? group_lr_host[i] : 0.f;
+        grp.wd[i] = i < ngroups ? group_wd_host[i] : 0.f;
+    }
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, beta1, beta2, eps, 1.f, 1.f,
+                       zero_grad, grp, (const int*)skip_flag, (const int*)step_in, (int*)step_out);
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -340,6 +340,24 @@ extern "C" int cy_yolo_decode(const float* logits, int B, int G, int A, int C, c
     return 0;
 }
 
+// Scratch (private-segment) bytes per lane of the per-target kernels, as the loaded code object reports them.  They must be
+// 0 for the heads to run on a side stream (models/engine.py): with their polygon arrays in scratch, assign / pairs returned
+// different owners and IoUs in ~1 % of launches whenever another kernel ran beside them (tools/head_race_probe.py; root cause
+// not found -- nothing reads an uninitialised or out-of-range array element, the suspects left are the runtime's per-queue
+// scratch provisioning under concurrent dispatch).  build.py checks the same figure at compile time.
+extern "C" int cy_head_scratch_bytes(void) {
+    CY_ENTER();
+    const void* fns[] = {(const void*)assign_kernel, (const void*)pairs_kernel<true>, (const void*)pairs_kernel<false>,
+                         (const void*)giou_grad_kernel};
+    int worst = 0;
+    for (const void* f : fns) {
+        hipFuncAttributes a;
+        if (hipFuncGetAttributes(&a, f) != hipSuccess) { (void)hipGetLastError(); return -2; }
+        if ((int)a.localSizeBytes > worst) worst = (int)a.localSizeBytes;
+    }
+    return worst;
+}
+
 extern "C" int64_t cy_yolo_loss_workspace(int B, int G, int A, int C, int nT) {
     (void)C;
     const long cells = (long)B * A * G * G;

@@ -6,7 +6,9 @@ reference, so a seeded run picks the same flips, holes and mosaic centres; pixel
 (cy_bev_flip_cutout / cy_bev_mosaic / cy_bev_mosaic_targets) and come out bit-identical.
 
 ``img``: float32 [3, H, W] device tensor (what ``kitti_bev_utils.makeBVFeature`` returns for a device input);
-``targets``: float32 [n, 8] = (sample, class, x, y, w, l, im, re), host or device (moved to the image's device)."""
+``targets``: float32 [n, 8] = (sample, class, x, y, w, l, im, re), host or device.  Every transform returns the targets on
+the image's device whether or not its random gate fired (a collate that concatenates samples must not see a host / device
+mix that depends on the draws); when nothing fires and the targets already live there, the very same objects come back."""
 import random
 
 import numpy as np
@@ -16,6 +18,7 @@ from .. import ops
 
 
 def _on(img, targets):
+    """targets on the image's device as contiguous float32 (the same object when it already is)."""
     ops.check_device_tensor(img, 'augmentation')
     return targets.to(img.device).float().contiguous()
 
@@ -28,6 +31,7 @@ class Compose(object):
         self.p = p
 
     def __call__(self, img, targets):
+        targets = _on(img, targets)
         if np.random.random() <= self.p:
             for t in self.transforms:
                 img, targets = t(img, targets)
@@ -42,6 +46,7 @@ class OneOf(object):
         self.p = p
 
     def __call__(self, img, targets):
+        targets = _on(img, targets)
         if np.random.random() <= self.p:
             choice = np.random.randint(low=0, high=len(self.transforms))
             img, targets = self.transforms[choice](img, targets)
@@ -53,8 +58,8 @@ class Horizontal_Flip(object):
         self.p = p
 
     def __call__(self, img, targets):
+        targets = _on(img, targets)
         if np.random.random() <= self.p:
-            targets = _on(img, targets)
             img, _ = ops.bev_flip_cutout(img.float().contiguous(), True, [], 0.0, targets)
         return img, targets
 
@@ -69,6 +74,7 @@ class Cutout(object):
         self.n_holes, self.ratio, self.fill_value, self.p = n_holes, ratio, fill_value, p
 
     def __call__(self, img, targets):
+        targets = _on(img, targets)
         if np.random.random() <= self.p:
             h, w = img.size(1), img.size(2)
             h_cutout, w_cutout = int(self.ratio * h), int(self.ratio * w)
@@ -77,7 +83,6 @@ class Cutout(object):
                 y, x = np.random.randint(h), np.random.randint(w)
                 holes.append((int(np.clip(y - h_cutout // 2, 0, h)), int(np.clip(y + h_cutout // 2, 0, h)),
                               int(np.clip(x - w_cutout // 2, 0, w)), int(np.clip(x + w_cutout // 2, 0, w))))
-            targets = _on(img, targets)
             # the kernel takes at most 8 holes per launch
             keep_all = None
             for k in range(0, max(len(holes), 1), 8):

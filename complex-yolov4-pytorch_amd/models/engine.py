@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from .. import ops
+from .. import ops, tune
 from ..ops import CONV_ACCUM, CONV_BIAS_F32OUT, CONV_STATS, CONV_TRANSPOSED, CY_F32, View
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1          # torch.nn.BatchNorm2d defaults, as the reference uses them
@@ -22,6 +22,9 @@ def _pad32(c):
 
 
 _CONV_TUNE_MEMO = {}      # (kind, shape key) -> best kernel / tile hint, shared by every engine of the process
+# tools/make_tune_cache.py only: lets the process that PRODUCES the persisted table time deterministic engines too (their
+# statistics-table layout differs, so they have keys of their own); everywhere else deterministic=True never times
+_DET_TIMING = os.environ.get('CY_TUNE_DET_TIMING') == '1'
 
 
 class Engine:
@@ -313,9 +316,17 @@ class Engine:
     def _f_add(self, rec, *_):
         ops.slice_add(self.view(rec['a']), self.view(rec['b']), self.view(rec['out']))
 
+    def _heads_side_ok(self):
+        """The heads may run beside the trunk only while their per-target kernels have no private segment in the code
+        object that is actually loaded (see cy_head_scratch_bytes); asked once."""
+        ok = getattr(self, '_heads_ok', None)
+        if ok is None:
+            ok = self._heads_ok = (not hasattr(ops, 'head_scratch_bytes')) or ops.head_scratch_bytes() == 0
+        return ok
+
     def _f_yolo(self, rec, targets, use_giou, img_size):
         if (self.side is not None and targets is not None and not self._in_side_head
-                and os.environ.get('CY_HEADS_SIDE', '1') != '0'):
+                and os.environ.get('CY_HEADS_SIDE', '1') != '0' and self._heads_side_ok()):
             # training: the decode + loss kernels of a head are a dozen two-wave launches (one lane per target in the
             # polygon clip), ~0.15 ms of latency that nothing downstream needs before the loss is read -- they run on the
             # side stream beside the trunk convs that follow the head (forward() joins the streams at the end): +1 %.
@@ -394,14 +405,17 @@ class Engine:
                     on_module_done(idx)
 
     def _autotune_wgrad(self):
-        """Pick the split-K factor of every weight-gradient launch by timing it (once, at the first backward; shapes are
-        static).  The heuristic of cy_conv_wgrad_split is within ~10-25 % of the best split for most layers but the
-        optimum depends on how tiles x split quantises over the CUs; cost = kernel time + the fold's share for the slabs.
-        CY_WGRAD_AUTOTUNE=0 keeps the heuristic."""
+        """Pick the split-K factor of every weight-gradient launch (once, at the first backward; shapes are static): a hit in
+        the persisted table (tune.py) is used as it is; otherwise the default mode times the candidates.  The heuristic of
+        cy_conv_wgrad_split is within ~10-25 % of the best split for most layers but the optimum depends on how
+        tiles x split quantises over the CUs; cost = kernel time + the fold's share for the slabs.  deterministic=True
+        never times (the split decides how the pixel sum is partitioned, i.e. the fp32 rounding): table or heuristic, both
+        functions of the shape alone.  CY_WGRAD_AUTOTUNE=0 keeps the heuristic."""
         self._wgrad_tuned = True
         if getattr(self.device, 'type', str(self.device)) != 'cuda' or os.environ.get('CY_WGRAD_AUTOTUNE', '1') == '0':
             return
         memo = {}
+        reps = int(os.environ.get('CY_TUNE_REPS', '3'))
         heads = {id(h['conv']): i for i, h in enumerate(self.plan.heads)}
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for rec in self.plan.convs:
@@ -409,27 +423,35 @@ class Engine:
             cop, cip, kk = _pad32(rec['cout']), rec['cin_pad'], rec['ks'] * rec['ks']
             dy = self.head_tmp[heads[id(rec)]] if id(rec) in heads else self.view(rec['out'], grad=True)
             xv = self.view(rec['x'])
-            key = (dy.N, dy.H, dy.W, dy.C, dy.ld, xv.H, xv.W, xv.C, xv.ld, rec['ks'], rec['stride'], rec['pad'])
+            key = ('wgrad', self.dt, dy.N, dy.H, dy.W, dy.C, dy.ld, xv.H, xv.W, xv.C, xv.ld, rec['ks'], rec['stride'], rec['pad'])
             if key not in memo:
                 s0, cap = self.wsplit[idx], self.wsplit_cap[idx]
-                cands = sorted({c for c in list(range(max(1, s0 // 3), min(cap, s0 + 8) + 1)) + [cap, (s0 + cap) // 2] if 1 <= c <= cap})
-                if len(cands) > 24:
-                    cands = sorted(set(cands[::max(1, len(cands) // 24)] + [s0]))
-                slab_us = cop * kk * cip * 4 / 2.5e6   # fold: ~2.5 TB/s over the slabs
-                best, best_cost = s0, None
-                off = self.wslab_off[idx]
-                for c in cands:
-                    part = self.wpart[off:off + c * cop * kk * cip]
-                    ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c)
-                    ev0.record()
-                    for _ in range(3):
+                hit = tune.get(key)
+                if hit is not None and 1 <= int(hit[0]) <= cap:
+                    memo[key] = int(hit[0])
+                    tune.put(key, *hit)
+                elif self.det and not _DET_TIMING:
+                    memo[key] = s0
+                else:
+                    cands = sorted({c for c in list(range(max(1, s0 // 3), min(cap, s0 + 8) + 1)) + [cap, (s0 + cap) // 2] if 1 <= c <= cap})
+                    if len(cands) > 24:
+                        cands = sorted(set(cands[::max(1, len(cands) // 24)] + [s0]))
+                    slab_us = cop * kk * cip * 4 / 2.5e6   # fold: ~2.5 TB/s over the slabs
+                    best, best_cost = s0, None
+                    off = self.wslab_off[idx]
+                    for c in cands:
+                        part = self.wpart[off:off + c * cop * kk * cip]
                         ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c)
-                    ev1.record()
-                    ev1.synchronize()
-                    cost = ev0.elapsed_time(ev1) * 1e3 / 3 + c * slab_us
-                    if best_cost is None or cost < best_cost:
-                        best, best_cost = c, cost
-                memo[key] = best
+                        ev0.record()
+                        for _ in range(reps):
+                            ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c)
+                        ev1.record()
+                        ev1.synchronize()
+                        cost = ev0.elapsed_time(ev1) * 1e3 / reps + c * slab_us
+                        if best_cost is None or cost < best_cost:
+                            best, best_cost = c, cost
+                    memo[key] = best
+                    tune.put(key, best, best_cost * 1e-3)
             self.wsplit[idx] = memo[key]
         self._reduce_groups = None
 
@@ -443,24 +465,36 @@ class Engine:
                 and os.environ.get('CY_CONV_AUTOTUNE', '1') != '0')
 
     def _time_hints(self, key, launch, cin, cout, ks=0):
-        """Best kernel / tile hint for one conv launch shape: time every candidate (1 warm-up + 3 launches between HIP
-        events) and keep the fastest.  The 4-wave and the 8-wave kernels are within +-10 % of each other on v4's layers and
+        """Best kernel / tile hint for one conv launch shape: looked up (tune.py) or timed (1 warm-up + CY_TUNE_REPS
+        launches per candidate between HIP events, the fastest kept).  The 4-wave and the 8-wave kernels are within +-10 % of each other on v4's layers and
         the winner depends on how tiles quantise over the 256 CUs, so it is measured, once per shape and process."""
         return self._time_hints_t(key, launch, cin, cout, ks=ks)[0]
 
-    def _time_hints_t(self, key, launch, cin, cout, pipe_only=False, ks=0):
-        """-> (best hint, its time in ms for 3 launches); pipe_only leaves the 4-wave kernels out and returns (None, None)
-        when the pipelined kernel does not take the shape."""
+    def _time_hints_t(self, key, launch, cin, cout, pipe_only=False, ks=0, hints=None):
+        """-> (best hint, its time in ms per launch); pipe_only leaves the 4-wave kernels out and returns (None, None)
+        when the pipelined kernel does not take the shape.  Order of authority: this process's memo, the persisted table
+        (tune.py), then -- default mode only -- a timing run over the candidates (``hints`` overrides the candidate list).
+        deterministic=True never times: a table miss takes hint 0, the library's shape-only default."""
         memo = _CONV_TUNE_MEMO.get(key)
         if memo is not None:
             return memo
-        hints = [] if pipe_only else [1]
-        if ks == 3 and cin in (8, 32) and not pipe_only:
-            hints.append(0)       # forward 3 -> 32 / 32 -> 64: the library default is the direct small-Cin kernel (conv_direct.hip)
-        if ks == 1 and (cin, cout) in ((64, 64), (128, 64), (64, 128), (64, 32), (32, 64)) and not pipe_only:
-            hints.append(10)      # 1x1 streams: the direct kernel, also below the library's own size threshold
-        if cin % 64 == 0 and cout % 8 == 0:
-            hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h in (3, 8) and cout <= 64)]
+        hit = tune.get(key)
+        if hit is not None:
+            hit = (hit[0], hit[1])
+            _CONV_TUNE_MEMO[key] = hit
+            tune.put(key, *hit)
+            return hit
+        if self.det and not _DET_TIMING:
+            return (None if pipe_only else 0, None)      # (not memoised: the key may be shared with default-mode engines)
+        if hints is None:
+            hints = [] if pipe_only else [1]
+            if ks == 3 and cin in (8, 32) and not pipe_only:
+                hints.append(0)       # forward 3 -> 32 / 32 -> 64: the library default is the direct small-Cin kernel (conv_direct.hip)
+            if ks == 1 and (cin, cout) in ((64, 64), (128, 64), (64, 128), (64, 32), (32, 64)) and not pipe_only:
+                hints.append(10)      # 1x1 streams: the direct kernel, also below the library's own size threshold
+            if cin % 64 == 0 and cout % 8 == 0:
+                hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h in (3, 8) and cout <= 64)]
+        reps = int(os.environ.get('CY_TUNE_REPS', '3'))
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best, best_t = (None if pipe_only else 1), None
         for h in hints:
@@ -471,14 +505,15 @@ class Engine:
                     break
                 raise
             ev0.record()
-            for _ in range(3):
+            for _ in range(reps):
                 launch(h)
             ev1.record()
             ev1.synchronize()
-            t = ev0.elapsed_time(ev1)
+            t = ev0.elapsed_time(ev1) / reps
             if best_t is None or t < best_t * 0.98:      # a challenger must win by 2 %: ties keep the earlier candidate
                 best, best_t = h, t
         _CONV_TUNE_MEMO[key] = (best, best_t)
+        tune.put(key, best, best_t)
         return best, best_t
 
     def _autotune_fwd(self):
@@ -552,7 +587,7 @@ class Engine:
                     continue
                 rows = ops.bn_bwd_rows(raw.M, raw.C, self.dt, False)
                 _, t_reduce = self._time_hints_t(('bn_bwd_reduce', act, self.dt, raw.M, raw.C, raw.ld, gv.ld), lambda h: ops.bn_act_bwd_reduce(
-                    raw, gv, vec[0], vec[1], vec[2], vec[3], act, tbl, rows), 0, 0)
+                    raw, gv, vec[0], vec[1], vec[2], vec[3], act, tbl, rows), 0, 0, hints=[1])
                 if t_fused < t_plain + t_reduce:
                     self._dgrad_sums[(rec['idx'], ref.c0)] = (L, fhint)
                     self._sums_fused.add(L['idx'])

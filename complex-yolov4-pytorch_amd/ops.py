@@ -295,6 +295,12 @@ def adam_multi(desc, blocks, beta1, beta2, eps, bc1, bc2, lrs, wds, zero_grad=Fa
                float(bc2), int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _p(skip_flag), _stream())
 
 
+def adam_multi_dev(desc, blocks, beta1, beta2, eps, step_in, step_out, lrs, wds, zero_grad=False, skip_flag=None):
+    """cy_adam_multi_dev: bias corrections from the device step counter (step_in -> step_out, int32 [1] each)."""
+    lib().call('cy_adam_multi_dev', _p(desc), _p(blocks), blocks.shape[0], float(beta1), float(beta2), float(eps), _p(step_in),
+               _p(step_out), int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _p(skip_flag), _stream())
+
+
 def nchw_to_nhwc(x, cpad, dt, out=None):
     _require_gpu()
     N, C, H, W = x.shape
@@ -493,6 +499,11 @@ def yolo_decode(logits, B, G, A, C, anchors_wh, img_size, out, rows_total, row_o
     flat = [v for a in anchors_wh for v in a[:2]]
     lib().call('cy_yolo_decode', _p(logits), B, G, A, C, _farr(flat), float(img_size), _p(out), rows_total, row_offset,
                _stream())
+
+
+def head_scratch_bytes():
+    """Private-segment bytes per lane of the per-target loss kernels (cy_head_scratch_bytes); 0 = safe beside other kernels."""
+    return int(lib().raw('cy_head_scratch_bytes')())
 
 
 def yolo_loss_workspace(B, G, A, C, nT):

@@ -15,6 +15,8 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._table = self._key = None
         self._steps = 0
+        self._step_dev = None          # int32 [2] ping-pong step counter, used while a device skip flag is attached
+        self._ping = 0
 
     def load_state_dict(self, state_dict):
         """torch.optim semantics plus what the fused step keeps outside ``state``: the bias-correction step count is
@@ -31,10 +33,13 @@ class FusedAdam(torch.optim.Optimizer):
         steps = [int(st['step']) for st in self.state.values() if 'step' in st]
         self._steps = max(steps) if steps else 0
         self._table = self._key = None
+        self._step_dev = None
 
     def note_skipped(self):
-        """A step the device skip flag suppressed (DynamicLossScale found a non-finite gradient) did not happen: take it
-        out of the bias-correction count."""
+        """A step the device skip flag suppressed (DynamicLossScale found a non-finite gradient) did not happen.  The
+        KERNEL already knew: with a skip flag attached the step count that feeds the bias corrections lives on the device
+        and only advances on applied steps (cy_adam_multi_dev), so no step ever runs with t + 1 in place of t.  This
+        only brings the host's copy (the ``step`` entries of ``state_dict()``) back in line, one step late."""
         self._steps = max(0, self._steps - 1)
         for st in self.state.values():
             st['step'] = self._steps
@@ -69,10 +74,19 @@ class FusedAdam(torch.optim.Optimizer):
         for st in self.state.values():
             st['step'] = self._steps
         assert len(self.param_groups) <= 8
+        skip = getattr(self, 'skip_flag', None)
+        lrs, wds = [g['lr'] for g in self.param_groups], [g['weight_decay'] for g in self.param_groups]
+        if skip is not None:
+            if self._step_dev is None:       # first step under a skip flag (or after a resume): seed the device counter
+                self._step_dev = torch.full((2,), self._steps - 1, dtype=torch.int32, device=skip.device)
+                self._ping = 0
+            i = self._ping
+            ops.adam_multi_dev(self._table[0], self._table[1], b1, b2, self.param_groups[0]['eps'], self._step_dev[i:i + 1],
+                               self._step_dev[1 - i:2 - i], lrs, wds, zero_grad=zero_grad, skip_flag=skip)
+            self._ping = 1 - i
+            return loss
         ops.adam_multi(self._table[0], self._table[1], b1, b2, self.param_groups[0]['eps'], 1 - b1 ** self._steps,
-                       1 - b2 ** self._steps, [g['lr'] for g in self.param_groups],
-                       [g['weight_decay'] for g in self.param_groups], zero_grad=zero_grad,
-                       skip_flag=getattr(self, 'skip_flag', None))
+                       1 - b2 ** self._steps, lrs, wds, zero_grad=zero_grad)
         return loss
 
 

@@ -9,15 +9,21 @@ from ..parallel import reduce_tensor, subdivisions_for  # noqa: F401
 
 def create_optimizer(configs, model):
     """The reference's three parameter groups (train_utils.py:21-50): everything that is neither a bias nor a conv weight
-    first (BatchNorm scales), then conv weights with ``configs.weight_decay``, then biases -- on the device the fused
-    multi-tensor optimizers (one launch per step), elsewhere their torch.optim twins."""
+    first (BatchNorm scales), then conv weights with ``configs.weight_decay``, then biases -- as the fused multi-tensor
+    optimizers (one HIP launch per step).  There is no silent fallback: parameters that are not on the HIP device raise,
+    unless the caller asks for the stock ``torch.optim`` classes with ``configs.fused_optimizer = False`` (what the CPU
+    plumbing tests do; torch.optim then also serves device parameters, at 327 launches per step)."""
+    from .. import ops
     net = getattr(model, 'module', model)
     groups = {'other': [], 'conv_weight': [], 'bias': []}
     for name, param in net.named_parameters():
         kind = 'bias' if '.bias' in name else ('conv_weight' if ('conv' in name and '.weight' in name) else 'other')
         groups[kind].append(param)
     first = groups['other']
-    fused = getattr(configs, 'fused_optimizer', True) and bool(first) and first[0].is_cuda
+    fused = bool(getattr(configs, 'fused_optimizer', True))
+    if fused and not (first and first[0].is_cuda):
+        raise ops.CyoloError('create_optimizer: the fused optimizers run on the HIP device only -- move the model to the '
+                             'device first (model.to(device)) or set configs.fused_optimizer = False for torch.optim')
     if configs.optimizer_type == 'adam':
         from ..optim import FusedAdam
         opt = (FusedAdam if fused else torch.optim.Adam)(first, lr=configs.lr)

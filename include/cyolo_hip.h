@@ -82,6 +82,13 @@ typedef struct {
 int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2, float eps,
                   float bias_corr1, float bias_corr2, int zero_grad, const float* group_lr_host,
                   const float* group_wd_host, int ngroups, const int32_t* skip_flag, cy_stream_t s);
+/* cy_adam_multi with the step count t kept on the device (dynamic loss scaling, where the host learns about a skipped
+ * step one step late): the bias corrections 1 - beta^t are computed in the kernel from t = *step_in + 1, and *step_out
+ * receives t -- or *step_in unchanged when *skip_flag is set.  A skipped step therefore never advances the bias correction,
+ * as torch.optim.Adam under torch.cuda.amp.GradScaler.  step_in and step_out are two distinct device int32 (ping-pong). */
+int cy_adam_multi_dev(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2, float eps,
+                      const int32_t* step_in, int32_t* step_out, int zero_grad, const float* group_lr_host,
+                      const float* group_wd_host, int ngroups, const int32_t* skip_flag, cy_stream_t s);
 /* Fused multi-tensor SGD with momentum / Nesterov (torch.optim.SGD semantics, dampening 0): the reference's other
  * optimizer choice (src/utils/train_utils.py:35-37: SGD(lr, momentum, nesterov=True)).  Uses cy_adam_desc with `m` as the
  * momentum buffer (`v` unused, may be NULL); first_step != 0 initialises the buffer with the gradient as torch does. */
@@ -278,6 +285,9 @@ int cy_fold_rows_out(int rows);
 int cy_yolo_decode(const float* logits, int B, int G, int A, int C, const float* anchors_host, float img_size,
                    float* out, int rows_total, int row_offset, cy_stream_t s);
 
+/* Scratch (private segment) bytes per lane of the per-target loss kernels in the loaded code object: 0 is the
+ * precondition for running cy_yolo_loss concurrently with other kernels (side stream); -2 = no device to ask. */
+int cy_head_scratch_bytes(void);
 /* Workspace size in bytes for cy_yolo_loss. */
 int64_t cy_yolo_loss_workspace(int B, int G, int A, int C, int nT);
 /* Fused build_targets + loss + metrics + d(loss)/d(logits) (yolo_layer.py:69-142, :199-251, and the

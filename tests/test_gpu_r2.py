@@ -29,18 +29,55 @@ def _model(cfg, dtype, **kw):
     return m.to(DEV)
 
 
-@pytest.mark.parametrize('tag,B,S', [('b16_608', 16, 608), ('b2_1024', 2, 1024)])
+# bounds on the element-wise gradient-head error of the fp32 parity mode (measured: see DESIGN.md section 4)
+ELEMWISE_MEDIAN = {'b16_608': 2e-2, 'b2_1024': 5e-2, 'b2_1216m': 5e-2}
+ELEMWISE_P90 = {'b16_608': 0.1, 'b2_1024': 0.25, 'b2_1216m': 0.25}
+MOSAIC_SEEDS = (3, 11)        # tests/golden/make_golden_big.py
+
+
+def mosaic_batch(g, key, seed0=60, B=2, half=608, nt=6):
+    """The b2_1216m case's input, assembled ON THE DEVICE (data_process.transformation.make_mosaic) from the same seeded
+    tiles and ``random`` seeds the reference's KittiDataset.load_mosaic got in make_golden_big.py; checked against the
+    golden's canvas sample and target rows (bit-identical) before it feeds the train step."""
+    import random
+    from complex_yolov4_pytorch_amd.data_process import transformation as T
+    canvases, rows = [], []
+    for b in range(B):
+        tiles = [syn.bev_images(1, half, seed=seed0 + 10 * b + k)[0].to(DEV) for k in range(4)]
+        tts = [syn.targets(1, nt, half, seed=seed0 + 10 * b + k) for k in range(4)]
+        random.seed(MOSAIC_SEEDS[b])
+        c, t = T.make_mosaic(tiles, tts, half, random_padding=True)
+        t[:, 0] = b
+        canvases.append(c); rows.append(t)
+    x, tg = torch.stack(canvases), torch.cat(rows, 0)
+    np.testing.assert_array_equal(x[:, :, ::97, ::89].cpu().numpy(), g[key + 'canvas_rows'])
+    np.testing.assert_array_equal(tg.cpu().numpy(), g[key + 'targets'])
+    return x, tg
+
+
+def grad_head_errors(model, ref_heads):
+    """Element-wise agreement of the first 8 entries of every parameter gradient with the reference's (``grad_head`` of the
+    goldens): per tensor max |g - ref| over max |ref| -> array over the 327 tensors."""
+    gh = np.stack([p.grad.reshape(-1)[:8].float().cpu().numpy() for _, p in model.named_parameters()])
+    return (np.abs(gh - ref_heads) / (np.abs(ref_heads).max(1, keepdims=True) + 1e-12)).max(1)
+
+
+@pytest.mark.parametrize('tag,B,S', [('b16_608', 16, 608), ('b2_1024', 2, 1024), ('b2_1216m', 2, 1216)])
 def test_v4_fp32_parity_at_baseline_shapes(golden, tag, B, S):
-    """BASELINE configs[1] (608x608, batch 16) and configs[4]'s resolution (1024x1024), fp32 parity mode, one train step
-    against THE REFERENCE's own result on the same seeded batch (tests/golden/darknet_big.npz, make_golden_big.py):
-    loss 1e-4 relative, probabilities 1e-3, the 18 metrics per head, every parameter-gradient tensor by norm, BatchNorm
-    running statistics."""
+    """BASELINE configs[1] (608x608, batch 16), configs[4]'s resolution (1024x1024) and configs[2]'s input (1216x1216 mosaic
+    canvases of four 608x608 maps, built by the device mosaic kernels), fp32 parity mode, one train step against THE
+    REFERENCE's own result on the same seeded batch (tests/golden/darknet_big.npz, make_golden_big.py): loss 1e-4 relative,
+    probabilities 1e-3, the 18 metrics per head, every parameter-gradient tensor by norm AND element-wise on the golden's
+    gradient heads, BatchNorm running statistics."""
     from tests.golden.make_golden import METRIC_KEYS
     g = golden('darknet_big')
     key = tag + '_'
     model = _model('complex_yolov4.cfg', 'f32', deterministic=True)
     model.train()
-    x, tg = syn.bev_images(B, S, seed=21), syn.targets(B, 6, S, seed=21)
+    if tag.endswith('m'):
+        x, tg = mosaic_batch(g, key)
+    else:
+        x, tg = syn.bev_images(B, S, seed=21), syn.targets(B, 6, S, seed=21)
     loss, out = model(x.to(DEV), tg.to(DEV))
     loss.backward()
     assert list(out.shape) == list(g[key + 'out_shape'])
@@ -63,6 +100,12 @@ def test_v4_fp32_parity_at_baseline_shapes(golden, tag, B, S):
     met = [[yl.metrics[k] for k in METRIC_KEYS] for yl in model.yolo_layers]
     np.testing.assert_allclose(met, g[key + 'metrics'], rtol=2e-3, atol=1e-5)
     assert abs(float(np.median(ratio)) - 1.0) < 5e-3 and 0.95 < ratio.min() and ratio.max() < 1.05
+    # element-wise (norms only).  Batch-16 BatchNorm conditions the net far better than the batch-1 case
+    # of test_gpu_model.py; what remains is the leaky-ReLU kink sensitivity of DESIGN.md section 4 on a few tensors
+    err = grad_head_errors(model, g[key + 'grad_head'])
+    print('   gradient heads (8 elements x 327 tensors) rel err: median %.2e, 90th pct %.2e, max %.2e'
+          % (float(np.median(err)), float(np.percentile(err, 90)), float(err.max())))
+    assert np.median(err) < ELEMWISE_MEDIAN[tag] and np.percentile(err, 90) < ELEMWISE_P90[tag]
     sd = model.state_dict()
     bn = np.stack([sd[str(n)][:8].cpu().numpy() for n in g[key + 'bn_names']])
     np.testing.assert_allclose(bn, g[key + 'bn_head'], rtol=5e-4, atol=1e-5)
@@ -229,8 +272,11 @@ def test_device_augmentation_matches_reference(golden):
     assert _sha(pi) == str(g['comp_sha'])
     np.testing.assert_array_equal(pt.cpu().numpy(), g['comp_targets'])
     np.random.seed(5)                                              # p gates: nothing happens, inputs returned untouched
-    ni, nt = T.Horizontal_Flip(p=0.0)(img, tg)
-    assert ni is img and nt is tg
+    tgd = tg.to(DEV)
+    ni, nt = T.Horizontal_Flip(p=0.0)(img, tgd)
+    assert ni is img and nt is tgd
+    _, nh = T.Cutout(n_holes=2, ratio=0.1, p=0.0)(img, tg)         # host targets come back on the device, gate fired or not
+    assert nh.is_cuda and torch.equal(nh.cpu(), tg)
     tiles = [syn.bev_images(1, 608, seed=60 + k)[0].to(DEV) for k in range(4)]
     tts = [syn.targets(1, 6, 608, seed=60 + k) for k in range(4)]
     for tag, rp in (('mosaic_fixed', False), ('mosaic_rand_a', True), ('mosaic_rand_b', True)):
