@@ -49,7 +49,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int tn = lid % p.ntiles, tm = lid / p.ntiles;
+    TapSet cls;
+    const int tn = lid % p.ntiles, tm = select_class(p, lid / p.ntiles, cls);
 
     // ---- per-thread staging coordinates --------------------------------------------------------
     // direct-to-LDS: the LDS image of a wave-instruction is lane-linear (base + lane*16), so the swizzle moves to
@@ -72,11 +73,11 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             if (m < p.M) {
                 const int n = m / ohw, rem = m - n * ohw;
                 const int ohc = rem / p.OWc;
-                const int oh = ohc * p.oh_mul + p.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
+                const int oh = ohc * p.oh_mul + cls.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + cls.ow_off;
                 const int xh = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
                 const int xw = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
-                for (int t = 0; t < p.ntaps; ++t) {
-                    const int kh = (p.kh_pack >> (2 * t)) & 3, kw = (p.kw_pack >> (2 * t)) & 3;
+                for (int t = 0; t < cls.ntaps; ++t) {
+                    const int kh = (cls.kh_pack >> (2 * t)) & 3, kw = (cls.kw_pack >> (2 * t)) & 3;
                     const int th = xh + ksign * kh, tw = xw + ksign * kw;
                     const bool ok = (((th | tw) & sh) == 0) & ((unsigned)(th >> sh) < (unsigned)p.GH) &
                                     ((unsigned)(tw >> sh) < (unsigned)p.GW);
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     const unsigned w_rstep = (unsigned)RS * (unsigned)p.K * (unsigned)sizeof(T);
     int k_c = chunk * CH, k_tap = 0;  // this thread's chunk: channel offset and tap within the K tile
     while (k_c >= p.GC) { k_c -= p.GC; ++k_tap; }
-    const int ntaps = p.ntaps;
+    const int ntaps = cls.ntaps;
     const int adv_tap = BK / p.GC, adv_c = BK - adv_tap * p.GC;
     // buffer descriptors: 32-bit byte offsets, and an out-of-range offset makes the DMA write zeros -- which is exactly
     // the zero fill padding / the K tail / dgrad holes need (a direct-to-LDS load cannot write a literal)
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         unsigned char* ws_w = xs_w + BM * 128;
         const bool kvalid = k_tap < ntaps;
         const int tsh = 2 * min(k_tap, 15);
-        const int kh = (p.kh_pack >> tsh) & 3, kw = (p.kw_pack >> tsh) & 3;
+        const int kh = (cls.kh_pack >> tsh) & 3, kw = (cls.kw_pack >> tsh) & 3;
         // source offset of this tap relative to tap (0,0), launch-uniform geometry, per-thread tap only when GC < BK
         const unsigned tap_delta = (unsigned)(ksign * (((kh >> sh) * p.GW + (kw >> sh)) * p.ldg) + k_c) * (unsigned)sizeof(T);
 #pragma unroll
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (p.ntaps * p.GC + BK - 1) / BK;
+    const int nkt = (cls.ntaps * p.GC + BK - 1) / BK;
     auto compute_tile = [&](int stage) {
         const unsigned char* xs = smem + stage * STAGE;
         const unsigned char* ws = xs + BM * 128;
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<T, BM, BN, NW, false>(p, acc, tm, tn, lid, smem);
+    igemm_epilogue<T, BM, BN, NW, false>(p, cls, acc, tm, tn, lid, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -205,7 +206,8 @@ __global__ void __launch_bounds__(256, 2) igemm_fast_kernel(const IgemmParams p)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int tn = lid % p.ntiles, tm = lid / p.ntiles;
+    TapSet cls;
+    const int tn = lid % p.ntiles, tm = select_class(p, lid / p.ntiles, cls);
 
     const int chunk = (lane & 7) ^ ((lane >> 3) & 7);
     const int rbase = wave * 8 + (lane >> 3);
@@ -233,11 +235,11 @@ __global__ void __launch_bounds__(256, 2) igemm_fast_kernel(const IgemmParams p)
             if (m < p.M) {
                 const int n = m / ohw, rem = m - n * ohw;
                 const int ohc = rem / p.OWc;
-                const int oh = ohc * p.oh_mul + p.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
+                const int oh = ohc * p.oh_mul + cls.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + cls.ow_off;
                 const int xh = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
                 const int xw = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
-                for (int t = 0; t < p.ntaps; ++t) {
-                    const int kh = (p.kh_pack >> (2 * t)) & 3, kw = (p.kw_pack >> (2 * t)) & 3;
+                for (int t = 0; t < cls.ntaps; ++t) {
+                    const int kh = (cls.kh_pack >> (2 * t)) & 3, kw = (cls.kw_pack >> (2 * t)) & 3;
                     const int th = xh + ksign * kh, tw = xw + ksign * kw;
                     const bool ok = (((th | tw) & sh) == 0) & ((unsigned)(th >> sh) < (unsigned)p.GH) &
                                     ((unsigned)(tw >> sh) < (unsigned)p.GW);
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(256, 2) igemm_fast_kernel(const IgemmParams p)
     unsigned x_soff = 0u, w_soff = 0u;
     auto next_offsets = [&]() {
         const int tsh = 2 * l_tap;
-        const int kh = (p.kh_pack >> tsh) & 3, kw = (p.kw_pack >> tsh) & 3;
+        const int kh = (cls.kh_pack >> tsh) & 3, kw = (cls.kw_pack >> tsh) & 3;
         x_soff = (unsigned)((ksign * (((kh >> sh) * p.GW + (kw >> sh)) * p.ldg) + l_c) * (int)sizeof(T) - dmin);
         w_soff = (unsigned)(((kh * p.ks + kw) * p.GC + l_c) * (int)sizeof(T));
     };
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__(256, 2) igemm_fast_kernel(const IgemmParams p)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = p.ntaps * (p.GC / BK);
+    const int nkt = cls.ntaps * (p.GC / BK);
     next_offsets();
 #pragma unroll
     for (int pc = 0; pc < NP; ++pc) issue_piece(pc, 0, 0);
@@ -339,13 +341,13 @@ __global__ void __launch_bounds__(256, 2) igemm_fast_kernel(const IgemmParams p)
     step((nkt - 1) & 1, false);
     __syncthreads();
 
-    igemm_epilogue<T, BM, BN, NW, false>(p, acc, tm, tn, lid, smem);
+    igemm_epilogue<T, BM, BN, NW, false>(p, cls, acc, tm, tn, lid, smem);
 }
 
 template <typename T, int BM, int BN>
 int launch_general(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
-    p.mtiles = (p.M + BM - 1) / BM;
+    p.mtiles = ((p.M + BM - 1) / BM) * p.ncls;
     p.ntiles = (p.OC + BN - 1) / BN;
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_done = false;
@@ -362,7 +364,7 @@ int launch_general(const IgemmParams& p0, hipStream_t s) {
 template <typename T, int BM, int BN>
 int launch_fast(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
-    p.mtiles = (p.M + BM - 1) / BM;
+    p.mtiles = ((p.M + BM - 1) / BM) * p.ncls;
     p.ntiles = (p.OC + BN - 1) / BN;
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_done = false;
@@ -413,7 +415,7 @@ inline void pick_tile(int M, int OC, int K, int esize, int& bm, int& bn) {
 template <typename T>
 int dispatch_tiles(const IgemmParams& p, hipStream_t s) {
     int bm, bn;
-    pick_tile(p.M, p.OC, p.ntaps * p.GC, (int)sizeof(T), bm, bn);
+    pick_tile(p.M * p.ncls, p.OC, p.ntaps * p.GC, (int)sizeof(T), bm, bn);
 #define CY_TILE(BM_, BN_) \
     if (bm == BM_ && bn == BN_) return launch<T, BM_, BN_>(p, s);
     CY_TILE(128, 128) CY_TILE(128, 64) CY_TILE(128, 32) CY_TILE(64, 128) CY_TILE(64, 64) CY_TILE(64, 32)
@@ -484,16 +486,19 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
         p.x_bias = gb + bias < 0xFFFFFF00ull ? (unsigned)bias : 0u;
     }
     p.OHc = OH; p.OWc = OW; p.oh_mul = p.ow_mul = 1; p.oh_off = p.ow_off = 0;
+    p.ncls = 1;
     p.ntaps = ks * ks; p.kh_pack = p.kw_pack = 0;
     for (int t = 0; t < ks * ks; ++t) {
         p.kh_pack |= (unsigned)(t / ks) << (2 * t);
         p.kw_pack |= (unsigned)(t % ks) << (2 * t);
     }
     if (!(p.transposed && stride == 2)) return dispatch(p, dtype, cy_s(s));
-    // stride-2 dgrad: an input-gradient pixel only sees the taps with (o + pad - k) even.  Four launches, one per
-    // (row, column) parity class, each over its own taps: 9 tap-visits in total instead of 36.
-    for (int ph = 0; ph < 2; ++ph)
-        for (int pw = 0; pw < 2; ++pw) {
+    // stride-2 dgrad: an input-gradient pixel only sees the taps with (o + pad - k) even: four (row, column) parity classes,
+    // each over its own taps -- 9 tap-visits in total instead of 36.
+    IgemmParams cls[4];
+    int ncls = 0;
+    for (int ph = 1; ph >= 0; --ph)          // (1,1), (1,0), (0,1), (0,0): 4, 2, 2, 1 taps for a 3x3 / pad 1 kernel
+        for (int pw = 1; pw >= 0; --pw) {
             IgemmParams q = p;
             q.OHc = (OH - ph + 1) / 2; q.OWc = (OW - pw + 1) / 2;
             if (q.OHc <= 0 || q.OWc <= 0) continue;
@@ -509,9 +514,28 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
                     ++q.ntaps;
                 }
             }
-            const int rc = dispatch(q, dtype, cy_s(s));
-            if (rc) return rc;
+            if (q.ntaps == 0) {
+                // (1x1 stride 2: only the (pad, pad) class receives anything; the others are zeros the caller's store / accumulate
+                // semantics still expect to be written) -- keep the class, a tap-less launch stores zeros
+            }
+            cls[ncls++] = q;
         }
+    // ONE launch when the four sub-lattices are congruent (OH, OW even -- every stride-2 conv of the Darknet cfgs) and every
+    // class has a tap: the grid interleaves the classes tile by tile, so a heavy (4-tap) and a light (1-tap) tile sit next to
+    // each other on every XCD and the launch pays one ramp and one tail instead of four.  CY_DGRAD_S2_MERGE=0: four launches.
+    static int merge = -1;
+    if (merge < 0) { const char* e = getenv("CY_DGRAD_S2_MERGE"); merge = e ? atoi(e) : 1; }
+    bool can = merge && ncls == 4 && !(OH & 1) && !(OW & 1);
+    for (int c = 0; c < ncls && can; ++c) can = cls[c].ntaps > 0;
+    if (can) {
+        IgemmParams q = cls[0];      // (the kernels derive every class's offsets and taps from its number: select_class)
+        q.ncls = 4;
+        return dispatch(q, dtype, cy_s(s));
+    }
+    for (int c = 0; c < ncls; ++c) {
+        const int rc = dispatch(cls[c], dtype, cy_s(s));
+        if (rc) return rc;
+    }
     return 0;
 }
 

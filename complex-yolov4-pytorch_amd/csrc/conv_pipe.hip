@@ -55,7 +55,8 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    const int tn = lid % p.ntiles, tm = lid / p.ntiles;
+    TapSet cls;
+    const int tn = lid % p.ntiles, tm = select_class(p, lid / p.ntiles, cls);
 
     // ---- per-row gather table (one thread per tile row; the staging threads pick their rows up from LDS) -------------
     const int ksign = p.transposed ? -1 : 1;
@@ -75,11 +76,11 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
             if (tid < p.bm_eff && m < p.M) {
                 const int n = m / ohw, rem = m - n * ohw;
                 const int ohc = rem / p.OWc;
-                const int oh = ohc * p.oh_mul + p.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
+                const int oh = ohc * p.oh_mul + cls.oh_off, ow = (rem - ohc * p.OWc) * p.ow_mul + cls.ow_off;
                 const int xh = p.transposed ? oh + p.pad : oh * p.stride - p.pad;
                 const int xw = p.transposed ? ow + p.pad : ow * p.stride - p.pad;
-                for (int t = 0; t < p.ntaps; ++t) {
-                    const int kh = (p.kh_pack >> (2 * t)) & 3, kw = (p.kw_pack >> (2 * t)) & 3;
+                for (int t = 0; t < cls.ntaps; ++t) {
+                    const int kh = (cls.kh_pack >> (2 * t)) & 3, kw = (cls.kw_pack >> (2 * t)) & 3;
                     const int th = xh + ksign * kh, tw = xw + ksign * kw;
                     const bool ok = (((th | tw) & sh) == 0) & ((unsigned)(th >> sh) < (unsigned)p.GH) &
                                     ((unsigned)(tw >> sh) < (unsigned)p.GW);
@@ -124,9 +125,9 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
     int ld_tap = 0;
     unsigned char* ld_dst = smem;
     auto begin_tile = [&](int stage) {      // scalar part of a tile's addresses (SGPRs), then advance the K position
-        const bool real = l_tap < p.ntaps;
+        const bool real = l_tap < cls.ntaps;
         const int tsh = 2 * (real ? l_tap : 0);
-        const int kh = (p.kh_pack >> tsh) & 3, kw = (p.kw_pack >> tsh) & 3;
+        const int kh = (cls.kh_pack >> tsh) & 3, kw = (cls.kw_pack >> tsh) & 3;
         x_soff = (unsigned)((ksign * (((kh >> sh) * p.GW + (kw >> sh)) * p.ldg) + l_c) * (int)sizeof(T) - dmin);
         w_soff = (unsigned)(((kh * p.ks + kw) * p.GC + l_c) * (int)sizeof(T));
         ld_tap = real ? l_tap : 31;         // bit 31 of the inverted tap mask is always set -> every row out of range
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
             }
     };
     // pieces of a tile spread over the 4 sub-steps of a K step: sub-step s issues [s * NP / 4, (s + 1) * NP / 4)
-    const int nkt = p.ntaps * (p.GC / BK);
+    const int nkt = cls.ntaps * (p.GC / BK);
 
     if constexpr (LOADERS > 0) {
         // Loader / compute split over the same 3-stage ring and the same barrier protocol: at the barrier that opens step kt
@@ -521,7 +522,7 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
 template <typename T, int BM, int BN, int WN, int NST, bool EPI_LDS, int LOADERS = 0>
 int pipe_launch(const IgemmParams& p0, hipStream_t s) {
     IgemmParams p = p0;
-    p.mtiles = (p.M + p.bm_eff - 1) / p.bm_eff;
+    p.mtiles = ((p.M + p.bm_eff - 1) / p.bm_eff) * p.ncls;
     p.ntiles = (p.OC + BN - 1) / BN;
     constexpr int smem = NST * (BM + BN) * 128 + BM * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
@@ -621,7 +622,7 @@ int cy_pipe_try(const cyk::IgemmParams& p0, int dtype, hipStream_t s, int* used)
     const bool split = hint >= 7 && hint <= 9;       // four loader waves + eight compute waves
     if (only == 192 && p.OC <= 64) only = 256;
     int cap = 0, bn = 0, eff = 0;
-    if (!pipe_policy(p.M, p.OC, only, cap, bn, eff)) return 0;
+    if (!pipe_policy(p.M * p.ncls, p.OC, only, cap, bn, eff)) return 0;
     if (g_pipe_cap) { cap = g_pipe_cap; bn = g_pipe_bn; eff = g_pipe_bm_eff ? g_pipe_bm_eff : cap; }
     if (eff > cap) return CY_ERR_ARG;
     p.bm_eff = eff;

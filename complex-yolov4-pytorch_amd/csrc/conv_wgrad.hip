@@ -26,7 +26,31 @@ struct WgradParams {
     int pps;  // pixels per split (multiple of BKP)
     unsigned x_bytes;  // extent of the X view (wgrad_dma_kernel's descriptor); 0 = offsets do not fit 32 bits
     int ncol_tiles, nco_tiles;
+    int atomic;        // 1: every split adds into slab 0 with fp32 atomics (one resident, pre-zeroed slab per layer) instead of
+                       // storing its own slab -- the split-K slabs' write + fold traffic goes away; order-dependent rounding
 };
+
+// one accumulator tile -> its slab (plain stores) or slab 0 (fp32 atomics, fire-and-forget)
+template <int TI, int TJ, int BCO, int BCI>
+__device__ __forceinline__ void wgrad_store(const WgradParams& p, const f32x4 (&acc)[TI][TJ], int sp, int co0, int col0, int wi, int wj,
+                                            int q16, int g) {
+    float* slab = p.part + (p.atomic ? (size_t)0 : (size_t)sp * p.CoRows * p.Ncols);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = col0 + wj * (BCI / 2) + j * 16 + q16;
+            if (col >= p.Ncols) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wi * (BCO / 2) + i * 16 + g * 4 + r;
+                if (co >= p.CoRows) continue;
+                float* dst = slab + (size_t)co * p.Ncols + col;
+                if (p.atomic) __hip_atomic_fetch_add(dst, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *dst = acc[i][j][r];
+            }
+        }
+}
 
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -229,19 +253,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     }
 
     // D[co = ... + g*4 + r][col = ... + q16]
-    float* slab = p.part + (size_t)sp * p.CoRows * p.Ncols;
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int col = col0 + wj * (BCI / 2) + j * 16 + q16;
-            if (col >= p.Ncols) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wi * (BCO / 2) + i * 16 + g * 4 + r;
-                if (co < p.CoRows) slab[(size_t)co * p.Ncols + col] = acc[i][j][r];
-            }
-        }
+    wgrad_store<TI, TJ, BCO, BCI>(p, acc, sp, co0, col0, wi, wj, q16, g);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -408,19 +420,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
         __syncthreads();
     }
 
-    float* slab = p.part + (size_t)sp * p.CoRows * p.Ncols;
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int col = col0 + wj * (BCI / 2) + j * 16 + q16;
-            if (col >= p.Ncols) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + wi * (BCO / 2) + i * 16 + g * 4 + r;
-                if (co < p.CoRows) slab[(size_t)co * p.Ncols + col] = acc[i][j][r];
-            }
-        }
+    wgrad_store<TI, TJ, BCO, BCI>(p, acc, sp, co0, col0, wi, wj, q16, g);
 }
 
 template <typename T, int BCO, int BCI>
@@ -540,6 +540,13 @@ __device__ __forceinline__ void fold_pairs(const cy_reduce_desc& d, long first_p
 #pragma unroll
             for (int t = 0; t < KK; ++t) acc[t] += src[(size_t)sp * slab + t * d.CiPad];
         }
+        if (d.flags & 1) {       // atomically accumulated slab (cy_conv_wgrad, atomic mode): leave it zeroed for the next step
+            float* z = const_cast<float*>(src);
+            for (int sp = sl; sp < d.split; sp += lanes) {
+#pragma unroll
+                for (int t = 0; t < KK; ++t) z[(size_t)sp * slab + t * d.CiPad] = 0.f;
+            }
+        }
     }
     if (KK == 1 && lanes == 1) {
         if (p < npairs) d.grad[p] = scale * acc[0] + (accumulate ? d.grad[p] : 0.f);
@@ -575,7 +582,11 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const cy_reduce
         const size_t slab = (size_t)d.CoRows * ncols;
         for (int t = 0; t < kk; ++t) {
             float sum = 0.f;
-            for (int sp = 0; sp < d.split; ++sp) sum += d.part[(size_t)sp * slab + (size_t)co * ncols + t * d.CiPad + ci];
+            for (int sp = 0; sp < d.split; ++sp) {
+                float* q = const_cast<float*>(d.part) + (size_t)sp * slab + (size_t)co * ncols + t * d.CiPad + ci;
+                sum += *q;
+                if (d.flags & 1) *q = 0.f;
+            }
             d.grad[p * kk + t] = scale * sum + (accumulate ? d.grad[p * kk + t] : 0.f);
         }
     }
@@ -624,6 +635,8 @@ extern "C" int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int 
     const int bkp = dtype == CY_F32 ? 32 : 64;
     p.pps = (((p.M + split - 1) / split) + bkp - 1) / bkp * bkp;
     p.x_bytes = 0;
+    p.atomic = (use_tr & 4) ? 1 : 0;
+    use_tr &= 3;
     if (dtype == CY_F32) return dispatch<float, false>(p, split, cy_s(s));
     {   // direct-to-LDS kernel; use_tr = 2 forces the register-staged kernel (A/B runs), as do offsets beyond 32 bits
         const size_t xb = (((size_t)N * XH * XW - 1) * ldx + Ci) * 2, ab = ((size_t)p.M + 128) * lddy * 2;

@@ -40,7 +40,38 @@ struct IgemmParams {
     int bm_eff;                   // conv_pipe.hip: pixels per tile actually used (<= the kernel's tile capacity)
     int stat_det;                 // statistics table: 0 = CY_STAT_BINS bins shared by the blocks (atomics, bin = tile % CY_STAT_BINS);
                                   // 1 = one row per pixel tile (one add per address onto zero: run-to-run deterministic)
+    // Stride-2 dgrad as ONE launch: the four (row, column) parity classes of the input-gradient lattice share the grid, pixel
+    // tile index & 3 = class (heaviest first: 4, 2, 2, 1 taps for 3x3 / pad 1), every class over M pixels of its own OHc x OWc
+    // sub-lattice (the host merges only when the four sub-lattices are congruent, i.e. OH and OW even).  1: an ordinary launch.
+    int ncls;
 };
+
+// What a block needs to know about ITS pixel lattice and taps: the launch's own (ordinary launches, one parity class per
+// launch) or, in a merged stride-2 dgrad, those of the class its tile index selects -- derived from the class number with a
+// few scalar instructions (no per-class tables in the kernel arguments: a dynamically indexed argument array would put the
+// whole parameter block into scratch memory).
+struct TapSet {
+    int oh_off, ow_off, ntaps;
+    unsigned kh_pack, kw_pack;
+};
+
+// -> the block's pixel-tile index inside its class
+__device__ __forceinline__ int select_class(const IgemmParams& p, int tm, TapSet& c) {
+    c.oh_off = p.oh_off; c.ow_off = p.ow_off; c.ntaps = p.ntaps; c.kh_pack = p.kh_pack; c.kw_pack = p.kw_pack;
+    if (p.ncls <= 1) return tm;
+    const int k = tm & 3, ph = 1 - (k >> 1), pw = 1 - (k & 1);
+    c.oh_off = ph; c.ow_off = pw; c.ntaps = 0; c.kh_pack = c.kw_pack = 0u;
+    for (int kh = 0; kh < p.ks; ++kh) {
+        if ((ph + p.pad - kh) & 1) continue;
+        for (int kw = 0; kw < p.ks; ++kw) {
+            if ((pw + p.pad - kw) & 1) continue;
+            c.kh_pack |= (unsigned)kh << (2 * c.ntaps);
+            c.kw_pack |= (unsigned)kw << (2 * c.ntaps);
+            ++c.ntaps;
+        }
+    }
+    return tm >> 2;
+}
 
 template <typename T>
 struct Mma;
@@ -124,8 +155,8 @@ __device__ __forceinline__ float half32_sum(float v) {
 // NW waves = 2 over channels x NW/2 over pixels.  smem: the block's LDS (free for reuse; SYNC_FIRST adds the barrier
 // that makes it so when the main loop does not end with one).
 template <typename T, int BM, int BN, int NW, bool SYNC_FIRST>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[BN / 32][BM / (8 * NW)], int tm, int tn,
-                                               int lid, unsigned char* smem) {
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, const TapSet& cls, f32x4 (&acc)[BN / 32][BM / (8 * NW)], int tm,
+                                               int tn, int lid, unsigned char* smem) {
     constexpr int NT = NW * 64, WMW = NW / 2, TI = BN / 32, TJ = BM / (16 * WMW);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave & 1, wm = wave >> 1;
@@ -185,7 +216,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         if (sublattice) {
             const int n = mj / ohw, rem = mj - n * ohw;
             const int ohc = rem / p.OWc;
-            m = (n * p.OH + ohc * p.oh_mul + p.oh_off) * p.OW + (rem - ohc * p.OWc) * p.ow_mul + p.ow_off;
+            m = (n * p.OH + ohc * p.oh_mul + cls.oh_off) * p.OW + (rem - ohc * p.OWc) * p.ow_mul + cls.ow_off;
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {

@@ -64,6 +64,7 @@ class Engine:
         max_stats = max_bnrows = max_c = 1
         max_wpart = 0
         self.wsplit, self.wslab_off, self.wsplit_cap = {}, {}, {}
+        self.watomic = {}          # conv idx -> split-K factor of its ATOMIC weight-gradient launch (all splits add into ONE slab)
         self._views, self._view_refs = {}, []
         self._wgrad_tuned = False
         for rec in plan.convs:
@@ -235,7 +236,7 @@ class Engine:
                 off = self.wslab_off[idx]
                 part = self.wpart[off:off + sp * cop * kk * cip]
                 items.append((part, self.grads['models.%d.conv%d.weight' % (idx, rec['n'])], sp, cop, cip, rec['ks'],
-                              rec['cout'], rec['cin']))
+                              rec['cout'], rec['cin'], 1 if idx in self.watomic else 0))
             desc, blocks = ops.make_reduce_table(items, self.device)
             self._reduce_groups.append(dict(last=g[-1]['idx'], mods=[r['idx'] for r in g], desc=desc, blocks=blocks))
         self._reduce_key = self.grads[next(iter(self.grads))].data_ptr()
@@ -427,7 +428,7 @@ class Engine:
             if key not in memo:
                 s0, cap = self.wsplit[idx], self.wsplit_cap[idx]
                 hit = tune.get(key)
-                if hit is not None and 1 <= int(hit[0]) <= cap:
+                if hit is not None and 1 <= abs(int(hit[0])) <= max(cap, 512) and not (self.det and int(hit[0]) < 0):
                     memo[key] = int(hit[0])
                     tune.put(key, *hit)
                 elif self.det and not _DET_TIMING:
@@ -439,20 +440,32 @@ class Engine:
                     slab_us = cop * kk * cip * 4 / 2.5e6   # fold: ~2.5 TB/s over the slabs
                     best, best_cost = s0, None
                     off = self.wslab_off[idx]
-                    for c in cands:
-                        part = self.wpart[off:off + c * cop * kk * cip]
-                        ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c)
-                        ev0.record()
-                        for _ in range(reps):
-                            ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c)
-                        ev1.record()
-                        ev1.synchronize()
-                        cost = ev0.elapsed_time(ev1) * 1e3 / reps + c * slab_us
-                        if best_cost is None or cost < best_cost:
-                            best, best_cost = c, cost
+                    # atomic mode (default mode only): every split adds into ONE resident slab -- the fold then reads a single
+                    # slab and writes zeros back (2 slab passes whatever the split), and more splits cost no memory
+                    am = os.environ.get('CY_WGRAD_ATOMIC', '1')
+                    modes = [False] if (self.det or am == '0') else ([True] if am == '2' else [False, True])
+                    for atomic in modes:
+                        for c in (cands if not atomic else sorted(set(cands + [2 * cands[-1], 4 * cands[-1]]))):
+                            if (c - 1) * 512 >= dy.M and c > 1:
+                                continue
+                            part = self.wpart[off:off + (1 if atomic else c) * cop * kk * cip]
+                            ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c, atomic=atomic)
+                            ev0.record()
+                            for _ in range(reps):
+                                ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c, atomic=atomic)
+                            ev1.record()
+                            ev1.synchronize()
+                            cost = ev0.elapsed_time(ev1) * 1e3 / reps + (2 if atomic else c) * slab_us
+                            if best_cost is None or cost < best_cost:
+                                best, best_cost = (-c if atomic else c), cost
                     memo[key] = best
                     tune.put(key, best, best_cost * 1e-3)
-            self.wsplit[idx] = memo[key]
+            if memo[key] < 0:
+                self.watomic[idx], self.wsplit[idx] = -memo[key], 1
+            else:
+                self.wsplit[idx] = memo[key]
+        if self.watomic:
+            self.wpart.zero_()        # atomic slabs start from zero (the timing launches added into them); the folds keep them so
         self._reduce_groups = None
 
     # ---- conv kernel / tile choice ---------------------------------------------------------------------
@@ -616,7 +629,10 @@ class Engine:
         off = self.wslab_off[idx]
         part = self.wpart[off:off + sp * cop * rec['ks'] * rec['ks'] * cip]
         with ops.prof('wgrad', *self._conv_work(rec)):
-            ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, sp)
+            if idx in self.watomic:
+                ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, self.watomic[idx], atomic=True)
+            else:
+                ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, sp)
 
     def _dgrad(self, rec, dy, runs):
         wd = self.wd[rec['idx']]

@@ -249,14 +249,16 @@ def make_reduce_table(items, device):
     """items: [(part tensor, grad tensor, split, CoRows, CiPad, ks, Co, Ci)]."""
     import struct
     raw, rows = b'', []
-    for i, (part, grad, split, corows, cip, ks, Co, Ci) in enumerate(items):
+    for i, item in enumerate(items):
+        part, grad, split, corows, cip, ks, Co, Ci = item[:8]
+        flags = int(item[8]) if len(item) > 8 else 0      # bit 0: zero the slab elements after reading (atomic wgrad mode)
         # the fold's unit is one (co, ci) pair with all its taps.  Layers with few pairs and many slabs (the first
         # stages: split-K up to 128) let 2-8 threads share a pair, each folding every lanes-th slab
         lanes = 1
         if ks in (1, 3) and Co * Ci < 65536:
             while lanes < 8 and split >= 16 * lanes:
                 lanes *= 2
-        raw += struct.pack('<QQiiiiiiii', part.data_ptr(), grad.data_ptr(), split, corows, cip, ks, Co, Ci, lanes, 0)
+        raw += struct.pack('<QQiiiiiiii', part.data_ptr(), grad.data_ptr(), split, corows, cip, ks, Co, Ci, lanes, flags)
         pb = 256 // lanes if ks in (1, 3) else 256
         rows += [(i, first // 32) for first in range(0, Co * Ci, pb)]
     desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
@@ -366,10 +368,11 @@ def wgrad_split(M, Co, Ci, ks):
     return lib().raw('cy_conv_wgrad_split')(M, Co, Ci, ks)
 
 
-def conv_wgrad(dy, x, ks, stride, pad, part, split, use_tr=1):
+def conv_wgrad(dy, x, ks, stride, pad, part, split, use_tr=1, atomic=False):
+    """atomic: every split adds into slab 0 (pre-zeroed) with fp32 atomics instead of writing its own slab."""
     _require_gpu()
     lib().call('cy_conv_wgrad', _p(dy), dy.N, dy.H, dy.W, dy.C, dy.ld, _p(x), x.H, x.W, x.C, x.ld, ks, stride, pad,
-               dy.dt, _p(part), split, use_tr, _stream())
+               dy.dt, _p(part), split, use_tr | (4 if atomic else 0), _stream())
 
 
 def wgrad_reduce(part, split, co_rows, ci_pad, ks, Co, Ci, scale, accumulate, grad):

@@ -63,7 +63,9 @@ typedef struct {
 typedef struct {
     const float* part; float* grad;
     int split, CoRows, CiPad, ks, Co, Ci;
-    int lanes, pad_;     /* threads sharing one (co, ci) pair, each folding every lanes-th slab: 1, 2, 4 or 8 (ks 1 / 3) */
+    int lanes, flags;    /* threads sharing one (co, ci) pair, each folding every lanes-th slab: 1, 2, 4 or 8 (ks 1 / 3);
+                          * flags bit 0: write zeros back over the slab elements just read (slabs of cy_conv_wgrad's
+                          * atomic mode stay resident and must be zero at the start of the next step) */
 } cy_reduce_desc;
 enum { CY_MULTI_ELEMS = 1024 };
 int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* blocks, int nblocks, int dtype, cy_stream_t s);
@@ -177,7 +179,11 @@ int cy_bn_scratch_rows(void);
 
 /* Weight gradient: part[sp][CoRows][ks*ks*Ci] = sum over the pixels of split sp of dy[p][co] * x[p (+) tap][ci].
  * dy: view (N,OH,OW,Co,lddy) ; x: view (N,XH,XW,Ci,ldx).  `split` partial slabs are written (not accumulated);
- * cy_wgrad_reduce folds them into the torch-layout gradient. */
+ * cy_wgrad_reduce folds them into the torch-layout gradient.
+ * use_tr: 1 = the default kernels (LDS transpose reads), 0 / 2 = test / A-B variants; + 4 = ATOMIC mode: the pixel range is
+ * still cut into `split` blocks per tile, but every block ADDS its tile into slab 0 with fp32 atomics (part must hold one
+ * zeroed slab; fold it with split = 1 and cy_reduce_desc.flags bit 0).  No slab traffic proportional to `split`; the
+ * sum's rounding depends on arrival order, so the deterministic mode never uses it. */
 int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int lddy, const void* x, int XH, int XW, int Ci,
                   int ldx, int ks, int stride, int pad, int dtype, float* part, int split, int use_tr, cy_stream_t s);
 /* Recommended split for the given problem (fills the chip, bounded slab memory). */

@@ -73,8 +73,11 @@ def make_reduce_table(items, device):
 
 
 def wgrad_reduce_multi(desc, blocks, scale, accumulate):
-    for part, grad, split, corows, cip, ks, Co, Ci in desc:
+    for item in desc:
+        part, grad, split, corows, cip, ks, Co, Ci = item[:8]
         wgrad_reduce(part, split, corows, cip, ks, Co, Ci, scale, accumulate, grad)
+        if len(item) > 8 and item[8] & 1:           # atomic-mode slab: left zeroed by the fold
+            part.view(-1)[:split * corows * ks * ks * cip].zero_()
 
 
 def conv_dgrad_bn_sums(g, w, wrows, out, ks, stride, pad, raw, mean, invstd, scale, shift, act, sums, flags=0, tile=0):

@@ -14,6 +14,7 @@ import sys
 import time
 
 os.environ['CY_TUNE_CACHE'] = '0'
+os.environ['CY_TUNE_DET_TIMING'] = '1'      # this process may time deterministic engines too (models/engine.py)
 os.environ.setdefault('CY_TUNE_REPS', '8')
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
@@ -57,10 +58,6 @@ def eval_case(dtype, B, S):
 def main():
     out = sys.argv[1]
     quick = '--quick' in sys.argv
-    # deterministic engines never time: their keys (the statistics-table layout is part of the forward key) are filled by
-    # timing them in a default-mode process with the deterministic flag forced into the key -- see Engine._time_hints_t;
-    # here: run the deterministic configuration with CY_TUNE_DET_TIMING=1, which lets this one process time them
-    os.environ['CY_TUNE_DET_TIMING'] = '1'
     cases = [('train', 'f16', 16, 608, False), ('train', 'f16', 16, 608, True)]
     if not quick:
         cases += [('train', 'bf16', 16, 608, False), ('train', 'bf16', 16, 608, True), ('eval', 'f16', 32, 608, False),
