@@ -272,7 +272,9 @@ struct PwCfg {
     static_assert(CIN % 16 == 0 && COUT % 32 == 0 && NCH % NT == 0 && SMEM <= 80 * 1024, "tile layout");
 };
 
-template <typename T, int CIN, int COUT, int SPW>
+// EXTRA: the input-gradient variants that read while they store -- gradient fan-in (CY_CONV_ACCUM) and / or the BatchNorm-backward
+// sums of the producer layer (CY_CONV_BNBWD_SUMS); a separate instantiation so that the forward / eval kernels keep their registers
+template <typename T, int CIN, int COUT, int SPW, bool EXTRA>
 __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) {
     typedef PwCfg<T, CIN, COUT, SPW> C;
     typedef typename Mma32<T>::frag frag;
@@ -296,8 +298,19 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
         }
     }
     const bool stats = (p.flags & CY_CONV_STATS) != 0, affine = (p.flags & CY_CONV_AFFINE_ACT) != 0;
-    const bool accum = (p.flags & CY_CONV_ACCUM) != 0;
-    if (affine)
+    const bool accum = EXTRA && (p.flags & CY_CONV_ACCUM) != 0, bnsum = EXTRA && (p.flags & CY_CONV_BNBWD_SUMS) != 0;
+    // store phase: lane -> (pixel lane / CPO + 64 / CPO * it, 16-byte chunk lane % CPO of the pass): the chunk is a lane constant
+    constexpr int CPO = C::CW / 8, NPASS = COUT / C::CW, NSI = 32 * CPO / 64;
+    const int cl8 = (lane % CPO) * 8;
+    // CY_CONV_BNBWD_SUMS (1x1 dgrad only): BatchNorm-backward sums of the layer whose output gradient this launch stores, as in
+    // conv_pipe.hip -- res / ldres = that layer's pre-BN tensor, aff_scale / aff_shift its affine, bn_mean / bn_invstd its statistics
+    // (its affine sits in LDS, where the eval epilogue keeps the layer's own: asc / ash)
+    float s1[EXTRA ? NPASS : 1][8], s2[EXTRA ? NPASS : 1][8];
+#pragma unroll
+    for (int q = 0; q < (EXTRA ? NPASS : 1); ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[q][e] = 0.f; s2[q][e] = 0.f; }
+    if (affine || (p.flags & CY_CONV_BNBWD_SUMS))
         for (int c = tid; c < COUT; c += C::NT) { asc[c] = p.aff_scale[min(c, p.OC - 1)]; ash[c] = p.aff_shift[min(c, p.OC - 1)]; }
     constexpr int NSB = (COUT + 63) / 64;
     float ssum[NSB], qsum[NSB];
@@ -328,6 +341,23 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        // epilogue operands (pre-BN tensor for the sums, stored gradient for a fan-in launch) of one (segment, channel pass) at a
+        // time: the first before the MFMAs, each next one while the previous is being stored
+        tx8 rawv[EXTRA ? NSI : 1], oldv[EXTRA ? NSI : 1];
+        auto prefetch = [&](int sq) {
+            const int s = sq / NPASS, q = sq - s * NPASS;
+#pragma unroll
+            for (int it = 0; it < NSI; ++it) {
+                const long m = m0 + (wave * SPW + s) * 32 + it * (64 / CPO) + lane / CPO;
+                const int co = q * C::CW + cl8;
+                const bool ok = m < M && co < p.OC;
+                rawv[it] = tx8{};
+                oldv[it] = tx8{};
+                if (bnsum && ok) rawv[it] = *reinterpret_cast<const tx8*>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldres + co);
+                if (accum && ok) oldv[it] = *reinterpret_cast<const tx8*>(reinterpret_cast<const T*>(p.o + (size_t)m * pixo) + co);
+            }
+        };
+        if constexpr (EXTRA) { if (bnsum || accum) prefetch(0); }
         f32x16 acc[SPW][C::NCB];
 #pragma unroll
         for (int s = 0; s < SPW; ++s)
@@ -338,6 +368,7 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
 #pragma unroll
         for (int j = 0; j < C::KS; ++j) {
             const int cch = 2 * j + half;
+            if constexpr (EXTRA) asm volatile("" ::: "memory");    // one K step's fragments at a time: this variant is short of registers
             frag a[C::NCB];
 #pragma unroll
             for (int cb = 0; cb < C::NCB; ++cb)
@@ -389,9 +420,8 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
                     ssum[C::CW == 64 ? pass : 0] += sv;
                     qsum[C::CW == 64 ? pass : 0] += qv;
                 }
-                constexpr int CPO = C::CW / 8;
 #pragma unroll
-                for (int it = 0; it < 32 * CPO / 64; ++it) {
+                for (int it = 0; it < NSI; ++it) {
                     const int idx = it * 64 + lane, px = idx / CPO, ch = idx - px * CPO;
                     const int co = pass * C::CW + ch * 8;
                     if (px >= nvalid || co >= p.OC) continue;
@@ -405,17 +435,69 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] += (float)rv[e];
                     }
-                    if (accum) {
-                        const tx8 ov = *reinterpret_cast<const tx8*>(dst);
+                    if constexpr (EXTRA) {
+                        if (accum) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] += (float)ov[e];
+                            for (int e = 0; e < 8; ++e) f[e] += (float)oldv[it][e];
+                        }
                     }
                     tx8 v;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (T)f[e];
                     *reinterpret_cast<tx8*>(dst) = v;
+                    if constexpr (EXTRA) if (bnsum) {
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(asc + co), c1 = *reinterpret_cast<const f32x4*>(asc + co + 4);
+                        const f32x4 h0 = *reinterpret_cast<const f32x4*>(ash + co), h1 = *reinterpret_cast<const f32x4*>(ash + co + 4);
+                        const float bsc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                        const float bsh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float x = (float)rawv[it][e];
+                            const float z = x * bsc[e] + bsh[e];
+                            const float dm = mish_grad<true>(z), dl = z > 0.f ? 1.f : 0.1f;
+                            const float dz = (float)v[e] * (p.act == CY_ACT_MISH ? dm : (p.act == CY_ACT_LEAKY ? dl : 1.f));
+                            s1[pass][e] += dz;
+                            s2[pass][e] += dz * x;
+                        }
+                    }
+                }
+                if constexpr (EXTRA) {
+                    if ((bnsum || accum) && s * NPASS + pass + 1 < SPW * NPASS) prefetch(s * NPASS + pass + 1);
                 }
             }
+        }
+    }
+    if (bnsum) {
+        // lanes with equal lane % CPO hold the same channels: fold them, the waves through LDS, one atomic per (channel, moment)
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int m = CPO; m < 64; m <<= 1) {
+                    s1[q][e] += __shfl_xor(s1[q][e], m);
+                    s2[q][e] += __shfl_xor(s2[q][e], m);
+                }
+            }
+        if (lane < CPO) {
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = q * C::CW + cl8 + e, ch = min(c, p.OC - 1);
+                    red[(wave * 2 + 0) * COUT + c] = s1[q][e];
+                    red[(wave * 2 + 1) * COUT + c] = (s2[q][e] - p.bn_mean[ch] * s1[q][e]) * p.bn_invstd[ch];
+                }
+        }
+        __syncthreads();
+        float* srow = p.stats + (size_t)(blockIdx.x & (CY_STAT_BINS - 1)) * 2 * p.OC;
+        for (int c = tid; c < 2 * COUT; c += C::NT) {
+            const int mom = c / COUT, co = c - mom * COUT;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::NWAVE; ++w) t += red[(w * 2 + mom) * COUT + co];
+            if (co < p.OC) atomicAdd(srow + mom * p.OC + co, t);
         }
     }
     if (stats) {
@@ -439,19 +521,285 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
     }
 }
 
-template <typename T, int CIN, int COUT, int SPW>
-int pw_launch(const IgemmParams& p, hipStream_t s) {
+template <typename T, int CIN, int COUT, int SPW, bool EXTRA>
+int pw_launch_x(const IgemmParams& p, hipStream_t s) {
     typedef PwCfg<T, CIN, COUT, SPW> C;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct1x1_kernel<T, CIN, COUT, SPW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct1x1_kernel<T, CIN, COUT, SPW, EXTRA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         attr_done = true;
     }
     const long tiles = (p.M + C::TP - 1) / C::TP;
     const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
-    hipLaunchKernelGGL((direct1x1_kernel<T, CIN, COUT, SPW>), dim3(grid), dim3(256), C::SMEM, s, p);
+    hipLaunchKernelGGL((direct1x1_kernel<T, CIN, COUT, SPW, EXTRA>), dim3(grid), dim3(256), C::SMEM, s, p);
     CY_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int CIN, int COUT, int SPW>
+int pw_launch(const IgemmParams& p, hipStream_t s) {
+    if (p.flags & (CY_CONV_ACCUM | CY_CONV_BNBWD_SUMS)) return pw_launch_x<T, CIN, COUT, SPW, true>(p, s);
+    return pw_launch_x<T, CIN, COUT, SPW, false>(p, s);
+}
+
+
+// ---- 3x3 / stride 2 / pad 1 input gradient, small channel counts (dX 32 <- dY 64 @304 -> 608) ------------------------------
+// The four parity classes of a stride-2 dgrad are stride-1 "convolutions" of dY with 1, 2, 2 and 4 taps whose outputs
+// interleave on the dX lattice.  On the implicit-GEMM kernels the 32 <- 64 layer is one to four K steps per tile -- all
+// prologue, gather table and epilogue: 315 us for 567 MB (the slowest launch of the train step) against an HBM floor of
+// ~115 us.  Here, like the forward direct kernel: persistent blocks over tiles of 8 x 64 dX pixels, the dgrad weights
+// [OC][9 * GC] resident in LDS, the (4 + 1) x (32 + 1) dY patch read once (next tile prefetched into registers), wave w owns
+// dY row w of the tile = dX rows 2w, 2w + 1: per dX row the two column classes are computed (32-pixel segments, K = taps * GC)
+// and interleaved in a wave-private fp32 LDS tile, so the row leaves as 64 consecutive pixels, 16 B per lane.  Optional
+// epilogues: gradient fan-in (read-add-store) and the BatchNorm-backward sums of the layer whose output gradient this is
+// (CY_CONV_BNBWD_SUMS, as in conv_pipe.hip: one read of that layer's pre-BN tensor instead of a separate reduce pass).
+template <typename T, int GC, int OC>
+struct S2Cfg {
+    static constexpr int THO = 8, TWO = 64, NWAVE = THO / 2, NT = NWAVE * 64;
+    static constexpr int PR = THO / 2 + 1, PC = TWO / 2 + 1;
+    static constexpr int PXB = GC * 2, CPP = GC / 8;
+    static constexpr int K = 9 * GC, WROW = K * 2 + 16, NCB = OC / 32;
+    static constexpr int W_BYTES = OC * WROW;
+    static constexpr int SROW = OC * 4 + 16;
+    static constexpr int ST_BYTES = NWAVE * TWO * SROW;
+    static constexpr int PATCH_BYTES = (PR * PC * PXB + 15) / 16 * 16;
+    static constexpr int P_BYTES = PATCH_BYTES > ST_BYTES ? PATCH_BYTES : ST_BYTES;
+    static constexpr int RED_BYTES = NWAVE * 2 * OC * 4;
+    static constexpr int SMEM = W_BYTES + P_BYTES + RED_BYTES;
+    static constexpr int NCH = PR * PC * CPP, NIT = (NCH + NT - 1) / NT;
+    static_assert((CPP == 8 || CPP == 16) && OC % 32 == 0 && SMEM <= 80 * 1024, "tile layout");
+};
+
+// physical 16-byte chunk of logical chunk c of patch column pcol: 16 consecutive columns x one logical chunk = 16 distinct
+// bank groups (128-byte pixels alternate bank halves, 256-byte pixels all start on bank 0)
+template <int CPP>
+__device__ __forceinline__ int s2swz(int c, int pcol) {
+    return CPP == 8 ? (c ^ ((pcol >> 1) & 7)) : (c ^ (pcol & 15));
+}
+
+template <typename T, int GC, int OC>
+__global__ void __launch_bounds__(256, 2) direct_s2dgrad_kernel(const IgemmParams p) {
+    typedef S2Cfg<T, GC, OC> C;
+    typedef typename Mma32<T>::frag frag;
+    typedef T tx8 __attribute__((ext_vector_type(8)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;
+    unsigned char* patch = smem + C::W_BYTES;
+    unsigned char* stage = patch;
+    float* red = reinterpret_cast<float*>(patch + C::P_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    {
+        constexpr int CPRW = C::K * 2 / 16;
+        for (int idx = tid; idx < OC * (CPRW + 1); idx += C::NT) {
+            const int row = idx / (CPRW + 1), ch = idx - row * (CPRW + 1);
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (ch < CPRW && row < p.wrows) v = *reinterpret_cast<const u32x4*>(p.w + (size_t)row * (C::K * 2) + ch * 16);
+            *reinterpret_cast<u32x4*>(wl + row * C::WROW + ch * 16) = v;
+        }
+    }
+    const bool accum = (p.flags & CY_CONV_ACCUM) != 0, bnsum = (p.flags & CY_CONV_BNBWD_SUMS) != 0;
+    const int tiles_x = (p.OW + C::TWO - 1) / C::TWO, tiles_y = (p.OH + C::THO - 1) / C::THO;
+    const int ntiles = p.N * tiles_y * tiles_x;
+    const size_t pixg = (size_t)p.ldg * 2, pixo = (size_t)p.ldo * 2;
+    // store phase: lane -> (pixel lane / CPO + 64 / CPO * it, 16-byte chunk lane % CPO): the chunk is a lane constant
+    constexpr int CPO = OC / 8, PPI = 64 / CPO;
+    const int cl8 = (lane % CPO) * 8;
+    float bsc[8], bsh[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bsc[e] = 0.f; bsh[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+    if (bnsum) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = min(cl8 + e, p.OC - 1);
+            bsc[e] = p.aff_scale[ch]; bsh[e] = p.aff_shift[ch];
+        }
+    }
+
+    u32x4 pre[C::NIT];
+    auto issue = [&](int tile) {
+        const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
+        const int a0 = (tr / tiles_x) * (C::THO / 2), b0 = (tr % tiles_x) * (C::TWO / 2);
+        const unsigned char* gimg = p.g + (size_t)n * p.GH * p.GW * pixg;
+#pragma unroll
+        for (int it = 0; it < C::NIT; ++it) {
+            const int idx = it * C::NT + tid;
+            const int c = idx % C::CPP, pp = idx / C::CPP;
+            const int prow = pp / C::PC, pcol = pp - prow * C::PC;
+            const int iy = a0 + prow, ix = b0 + pcol;
+            pre[it] = u32x4{0u, 0u, 0u, 0u};
+            if (idx < C::NCH && iy < p.GH && ix < p.GW)
+                pre[it] = *reinterpret_cast<const u32x4*>(gimg + ((size_t)iy * p.GW + ix) * pixg + c * 16);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x), tr = tile - n * (tiles_y * tiles_x);
+        const int y0 = (tr / tiles_x) * C::THO, x0 = (tr % tiles_x) * C::TWO;
+        __syncthreads();      // the previous tile's store tiles (same LDS) are done; first trip: weights in place after the next one
+#pragma unroll
+        for (int it = 0; it < C::NIT; ++it) {
+            const int idx = it * C::NT + tid;
+            const int c = idx % C::CPP, pp = idx / C::CPP;
+            const int pcol = pp % C::PC;
+            if (idx < C::NCH) *reinterpret_cast<u32x4*>(patch + pp * C::PXB + s2swz<C::CPP>(c, pcol) * 16) = pre[it];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        // epilogue operands of this wave's dX rows (the producer layer's pre-BN tensor for the sums, the gradient already
+        // stored for a fan-in launch): the first row's are requested NOW, so that their latency hides behind the MFMAs; the
+        // second row's once the first row's are consumed
+        constexpr int NSI = C::TWO / PPI;          // store instructions per dX row
+        tx8 rawv[NSI], oldv[NSI];
+        auto prefetch = [&](int ph) {
+            const int oy = y0 + 2 * wave + ph;
+#pragma unroll
+            for (int it = 0; it < NSI; ++it) {
+                const int px = it * PPI + lane / CPO;
+                const bool ok = oy < p.OH && x0 + px < p.OW && cl8 < p.OC;
+                const size_t opix = ((size_t)n * p.OH + oy) * p.OW + x0 + px;
+                rawv[it] = tx8{};
+                oldv[it] = tx8{};
+                if (bnsum && ok) rawv[it] = *reinterpret_cast<const tx8*>(reinterpret_cast<const T*>(p.res) + opix * p.ldres + cl8);
+                if (accum && ok) oldv[it] = *reinterpret_cast<const tx8*>(reinterpret_cast<const T*>(p.o + opix * pixo) + cl8);
+            }
+        };
+        if (bnsum || accum) prefetch(0);
+        // ---- MFMA: acc[ph][pw][cb] = class (ph, pw) of dY row `wave`: 32 dX pixels (x = x0 + 2 l31 + pw) x 32 channels ------
+        f32x16 acc[2][2][C::NCB];
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                for (int cb = 0; cb < C::NCB; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc[ph][pw][cb][t] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ph = (kh & 1) ^ 1;                    // taps with (ph + 1 - kh) even
+            const int dh = (ph + 1 - kh) >> 1;              // dY row of dX row 2a + ph under tap kh: a + dh
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int pw = (kw & 1) ^ 1, dw = (pw + 1 - kw) >> 1;
+                const int pcol = l31 + dw;
+                const unsigned char* prow = patch + ((wave + dh) * C::PC + pcol) * C::PXB;
+                asm volatile("" ::: "memory");      // one tap's fragments at a time (hipcc otherwise hoists all 72 reads: spills)
+#pragma unroll
+                for (int j = 0; j < GC / 16; ++j) {
+                    const frag b = *reinterpret_cast<const frag*>(prow + s2swz<C::CPP>(2 * j + half, pcol) * 16);
+#pragma unroll
+                    for (int cb = 0; cb < C::NCB; ++cb) {
+                        const frag a = *reinterpret_cast<const frag*>(wl + (cb * 32 + l31) * C::WROW + ((kh * 3 + kw) * GC + j * 16) * 2 + half * 16);
+                        acc[ph][pw][cb] = Mma32<T>::mma(a, b, acc[ph][pw][cb]);
+                    }
+                }
+            }
+        }
+        __syncthreads();      // every wave is done with the patch: its LDS becomes the store tiles
+        unsigned char* wst = stage + wave * (C::TWO * C::SROW);
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int oy = y0 + 2 * wave + ph;
+            // both column classes of the row -> [64 pixels][OC] fp32, pixel 2 l31 + pw
+#pragma unroll
+            for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                for (int cb = 0; cb < C::NCB; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[r] = acc[ph][pw][cb][4 * g + r];
+                        *reinterpret_cast<f32x4*>(wst + (2 * l31 + pw) * C::SROW + (cb * 32 + 8 * g + 4 * half) * 4) = h;
+                    }
+            // (wave-private tile: the wave's own ds_writes are ordered before its ds_reads by lgkmcnt)
+            const int nvalid = oy < p.OH ? min(C::TWO, max(0, p.OW - x0)) : 0;
+#pragma unroll
+            for (int it = 0; it < NSI; ++it) {
+                const int px = it * PPI + lane / CPO;
+                if (px >= nvalid || cl8 >= p.OC) continue;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(wst + px * C::SROW + cl8 * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(wst + px * C::SROW + cl8 * 4 + 16);
+                float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const size_t opix = ((size_t)n * p.OH + oy) * p.OW + x0 + px;
+                if (accum) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += (float)oldv[it][e];
+                }
+                tx8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (T)f[e];
+                *reinterpret_cast<tx8*>(reinterpret_cast<T*>(p.o + opix * pixo) + cl8) = v;
+                if (bnsum) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (float)rawv[it][e];
+                        const float z = x * bsc[e] + bsh[e];
+                        const float dm = mish_grad<true>(z), dl = z > 0.f ? 1.f : 0.1f;
+                        const float dz = (float)v[e] * (p.act == CY_ACT_MISH ? dm : (p.act == CY_ACT_LEAKY ? dl : 1.f));
+                        s1[e] += dz;
+                        s2[e] += dz * x;
+                    }
+                }
+            }
+            if (ph == 0 && (bnsum || accum)) prefetch(1);
+        }
+    }
+    if (bnsum) {
+        // lanes with equal lane % CPO hold the same 8 channels: fold them, then the waves through LDS, then one atomic per
+        // (channel, moment) of the block into one of the CY_STAT_BINS rows -- the table layout of the forward statistics
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int m = CPO; m < 64; m <<= 1) {
+                s1[e] += __shfl_xor(s1[e], m);
+                s2[e] += __shfl_xor(s2[e], m);
+            }
+        }
+        if (lane < CPO) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = min(cl8 + e, p.OC - 1);
+                red[(wave * 2 + 0) * OC + cl8 + e] = s1[e];
+                red[(wave * 2 + 1) * OC + cl8 + e] = (s2[e] - p.bn_mean[ch] * s1[e]) * p.bn_invstd[ch];
+            }
+        }
+        __syncthreads();
+        float* srow = p.stats + (size_t)(blockIdx.x & (CY_STAT_BINS - 1)) * 2 * p.OC;
+        for (int c = tid; c < 2 * OC; c += C::NT) {
+            const int mom = c / OC, co = c - mom * OC;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::NWAVE; ++w) t += red[(w * 2 + mom) * OC + co];
+            if (co < p.OC) atomicAdd(srow + mom * p.OC + co, t);
+        }
+    }
+}
+
+template <typename T, int GC, int OC>
+int s2dgrad_launch(const IgemmParams& p, hipStream_t s) {
+    typedef S2Cfg<T, GC, OC> C;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_s2dgrad_kernel<T, GC, OC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        attr_done = true;
+    }
+    const long tiles = (long)p.N * ((p.OH + C::THO - 1) / C::THO) * ((p.OW + C::TWO - 1) / C::TWO);
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
+    hipLaunchKernelGGL((direct_s2dgrad_kernel<T, GC, OC>), dim3(grid), dim3(C::NT), C::SMEM, s, p);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int s2dgrad_dispatch(const IgemmParams& p, hipStream_t s, int* used) {
+    *used = 1;
+    if (p.GC == 64 && p.OC == 32) return s2dgrad_launch<T, 64, 32>(p, s);
+    *used = 0;
     return 0;
 }
 
@@ -493,18 +841,29 @@ int cy_direct_try(const cyk::IgemmParams& p, int dtype, hipStream_t s, int* used
     }
     const int hint = (p.flags >> CY_CONV_TILE_SHIFT) & 15;
     if (!g_direct_mode || hint == 1 || (dtype != CY_F16 && dtype != CY_BF16)) return 0;
-    if (p.stat_det || (p.flags & (CY_CONV_BIAS_F32OUT | CY_CONV_BNBWD_SUMS))) return 0;
+    if (p.stat_det || (p.flags & CY_CONV_BIAS_F32OUT)) return 0;
     if (p.ldg % 8 || p.ldo % 8 || ((uintptr_t)p.g & 15) || ((uintptr_t)p.o & 15) || ((uintptr_t)p.w & 15)) return 0;
     if (p.res && (p.ldres % 8 || ((uintptr_t)p.res & 15))) return 0;
+    if (p.transposed && p.stride == 2 && p.ks == 3 && p.pad == 1 && p.ncls == 4) {
+        // the whole stride-2 input gradient (all four parity classes) of the small-channel layers
+        // (taken without a hint or with hint 10; the capacity hints 2-9 name the pipelined kernel)
+        if (hint != 0 && hint != 10) return 0;
+        if ((p.flags & (CY_CONV_STATS | CY_CONV_AFFINE_ACT)) || p.OH != 2 * p.GH || p.OW != 2 * p.GW || p.OC % 8) return 0;
+        const int rc = dtype == CY_F16 ? s2dgrad_dispatch<f16>(p, s, used) : s2dgrad_dispatch<bf16>(p, s, used);
+        if (rc == 0 && *used) ++g_direct_launches;
+        return rc;
+    }
     if (p.ks == 1 && p.stride == 1 && p.pad == 0) {
         // 1x1 streams: worth it where the launch is long enough to fill the persistent grid several times over (the 152 / 304
         // grids at batch 16); smaller launches stay with the implicit-GEMM kernels unless the caller asks (hint 10)
         if (p.M < 256L * 1024 && hint != 10) return 0;
         if (p.OH != p.GH || p.OW != p.GW) return 0;
+        if ((p.flags & CY_CONV_BNBWD_SUMS) && (p.flags & (CY_CONV_STATS | CY_CONV_AFFINE_ACT))) return 0;
         const int rc = dtype == CY_F16 ? pw_dispatch<f16>(p, s, used) : pw_dispatch<bf16>(p, s, used);
         if (rc == 0 && *used) ++g_direct_launches;
         return rc;
     }
+    if (p.flags & CY_CONV_BNBWD_SUMS) return 0;
     if (p.ks != 3 || p.pad != 1 || p.transposed || (p.flags & CY_CONV_ACCUM)) return 0;
     if (p.OH != (p.GH + 2 - 3) / p.stride + 1 || p.OW != (p.GW + 2 - 3) / p.stride + 1) return 0;
     const int rc = dtype == CY_F16 ? direct_dispatch<f16>(p, s, used) : direct_dispatch<bf16>(p, s, used);

@@ -474,8 +474,8 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
     p.mtiles = p.ntiles = 0; p.bm_eff = 0;
     p.stat_det = (flags & CY_CONV_STATS_DET) ? 1 : 0;
     if (p.M <= 0 || OC <= 0) return CY_ERR_ARG;
-    if ((flags & CY_CONV_BNBWD_SUMS) && (!bn_mean || stride != 1 || (flags & (CY_CONV_STATS | CY_CONV_AFFINE_ACT | CY_CONV_BIAS_F32OUT))))
-        return CY_ERR_ARG;
+    if ((flags & CY_CONV_BNBWD_SUMS) && (!bn_mean || (flags & (CY_CONV_STATS | CY_CONV_AFFINE_ACT | CY_CONV_BIAS_F32OUT))))
+        return CY_ERR_ARG;      // (stride 2: only the direct small-channel kernel has the epilogue; dispatch() says so)
     if (stats_rows_host) *stats_rows_host = (flags & CY_CONV_STATS_DET) ? cy_conv_stats_rows_det(p.M, OC) : cy_conv_stats_rows(p.M, OC);
     const size_t esz = dtype == CY_F32 ? 4 : 2;
     const size_t gb = (((size_t)N * GH * GW - 1) * ldg + GC) * esz, wb = (size_t)wrows * p.K * esz;
@@ -532,6 +532,7 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
         q.ncls = 4;
         return dispatch(q, dtype, cy_s(s));
     }
+    if (flags & CY_CONV_BNBWD_SUMS) return CY_ERR_ARG;      // the sums ride on a single launch only
     for (int c = 0; c < ncls; ++c) {
         const int rc = dispatch(cls[c], dtype, cy_s(s));
         if (rc) return rc;

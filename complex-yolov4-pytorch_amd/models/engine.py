@@ -21,6 +21,7 @@ def _pad32(c):
     return (c + 31) // 32 * 32
 
 
+_PW_DIRECT = ((64, 64), (128, 64), (64, 128), (64, 32), (32, 64))    # (Cin, Cout) of the 1x1 streaming kernel (conv_direct.hip)
 _CONV_TUNE_MEMO = {}      # (kind, shape key) -> best kernel / tile hint, shared by every engine of the process
 # tools/make_tune_cache.py only: lets the process that PRODUCES the persisted table time deterministic engines too (their
 # statistics-table layout differs, so they have keys of their own); everywhere else deterministic=True never times
@@ -483,7 +484,7 @@ class Engine:
         the winner depends on how tiles quantise over the 256 CUs, so it is measured, once per shape and process."""
         return self._time_hints_t(key, launch, cin, cout, ks=ks)[0]
 
-    def _time_hints_t(self, key, launch, cin, cout, pipe_only=False, ks=0, hints=None):
+    def _time_hints_t(self, key, launch, cin, cout, pipe_only=False, ks=0, hints=None, extra=()):
         """-> (best hint, its time in ms per launch); pipe_only leaves the 4-wave kernels out and returns (None, None)
         when the pipelined kernel does not take the shape.  Order of authority: this process's memo, the persisted table
         (tune.py), then -- default mode only -- a timing run over the candidates (``hints`` overrides the candidate list).
@@ -500,10 +501,10 @@ class Engine:
         if self.det and not _DET_TIMING:
             return (None if pipe_only else 0, None)      # (not memoised: the key may be shared with default-mode engines)
         if hints is None:
-            hints = [] if pipe_only else [1]
+            hints = list(extra) + ([] if pipe_only else [1])
             if ks == 3 and cin in (8, 32) and not pipe_only:
                 hints.append(0)       # forward 3 -> 32 / 32 -> 64: the library default is the direct small-Cin kernel (conv_direct.hip)
-            if ks == 1 and (cin, cout) in ((64, 64), (128, 64), (64, 128), (64, 32), (32, 64)) and not pipe_only:
+            if ks == 1 and (cin, cout) in _PW_DIRECT and not pipe_only:
                 hints.append(10)      # 1x1 streams: the direct kernel, also below the library's own size threshold
             if cin % 64 == 0 and cout % 8 == 0:
                 hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h in (3, 8) and cout <= 64)]
@@ -514,6 +515,8 @@ class Engine:
             try:
                 launch(h)
             except ops.CyoloError:
+                if h in extra:
+                    continue          # an optional kernel that does not take this shape
                 if pipe_only:
                     break
                 raise
@@ -583,9 +586,12 @@ class Engine:
                 key = ('dgrad', self.dt, dy.N, dy.H, dy.W, dy.C, dy.ld, gv.H, gv.W, gv.C, gv.ld, rec['ks'], rec['stride'], acc)
                 # (timing an accumulating launch adds garbage into a gradient buffer that the real backward has not written
                 # yet at this point: every first writer of the step stores)
+                # stride-2 3x3: hint 10 = the direct small-channel kernel (conv_direct.hip) where it takes the shape; every other
+                # hint runs the four parity classes as one launch of the implicit-GEMM kernels
+                s2 = (10,) if (rec['ks'] == 3 and rec['stride'] == 2 and dy.C == 64 and ref.C == 32) else ()
                 hint, t_plain = self._time_hints_t(key, lambda h: ops.conv_igemm(
                     dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], flags=flags, tile=h), dy.C, ref.C,
-                    ks=(1 if rec['ks'] == 1 and rec['stride'] == 1 else 0))
+                    ks=(1 if rec['ks'] == 1 and rec['stride'] == 1 else 0), extra=s2)
                 self._dgrad_tile[(rec['idx'], ref.c0)] = hint
                 L = b.get('dx_sums', {}).get(ri) if can_fuse else None
                 if L is None:
@@ -595,12 +601,17 @@ class Engine:
                 tbl = self.bnpart_pair[0]
                 fhint, t_fused = self._time_hints_t(('dgrad+sums', act, raw.ld) + key[1:], lambda h: ops.conv_dgrad_bn_sums(
                     dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], raw, vec[0], vec[1], vec[2], vec[3],
-                    act, tbl, flags=flags, tile=h), dy.C, ref.C, pipe_only=True)
+                    act, tbl, flags=flags, tile=h), dy.C, ref.C, pipe_only=True,
+                    extra=s2 or ((10,) if (rec['ks'] == 1 and rec['stride'] == 1 and (dy.C, ref.C) in _PW_DIRECT) else ()))
                 if fhint is None:
                     continue
                 rows = ops.bn_bwd_rows(raw.M, raw.C, self.dt, False)
                 _, t_reduce = self._time_hints_t(('bn_bwd_reduce', act, self.dt, raw.M, raw.C, raw.ld, gv.ld), lambda h: ops.bn_act_bwd_reduce(
                     raw, gv, vec[0], vec[1], vec[2], vec[3], act, tbl, rows), 0, 0, hints=[1])
+                if os.environ.get('CY_TUNE_VERBOSE'):
+                    print('dgrad+sums L%d <- conv %d (k%d s%d %d->%d @%d): plain hint %s %.1f us + reduce %.1f us vs fused hint %s %.1f us'
+                          % (L['idx'], rec['idx'], rec['ks'], rec['stride'], dy.C, ref.C, gv.H, hint, 1e3 * t_plain, 1e3 * t_reduce,
+                             fhint, 1e3 * t_fused), flush=True)
                 if t_fused < t_plain + t_reduce:
                     self._dgrad_sums[(rec['idx'], ref.c0)] = (L, fhint)
                     self._sums_fused.add(L['idx'])

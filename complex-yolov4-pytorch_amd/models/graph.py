@@ -363,7 +363,7 @@ class Plan:
 
     def _mark_dgrad_bn_sums(self):
         """Which input-gradient launches may take the BatchNorm-backward sums of the layer that produced their output
-        tensor (cy_conv_dgrad_bn_sums): the stride-1 dgrad run of conv P that is the LAST writer of every channel of
+        tensor (cy_conv_dgrad_bn_sums): the dgrad run of conv P that is the LAST writer of every channel of
         dL/d(out of BN conv L), covers exactly that tensor, with P and L adjacent among the conv backward ops (the engine's
         alternating sum tables rely on that).  Marks ``b_P['dx_sums'][run index] = L's record`` and
         ``b_L['sums_from'] = P's index``; the engine decides per layer whether to use it."""
@@ -380,8 +380,8 @@ class Plan:
                 if w is not None and w[1] == 'dgrad' and w[0] == prev_conv:
                     pb = self.bwd[w[0]]
                     ref, _ = pb['dx'][w[2]]
-                    if (ref.st is out.st and ref.c0 == out.c0 and ref.C == out.C and pb['fwd']['stride'] == 1
-                            and L['cout'] % 8 == 0):
+                    # (a stride-2 consumer qualifies too since its four parity classes run as ONE launch)
+                    if ref.st is out.st and ref.c0 == out.c0 and ref.C == out.C and L['cout'] % 8 == 0:
                         pb.setdefault('dx_sums', {})[w[2]] = L
                         b['sums_from'] = pb['fwd']['idx']
             if op in ('conv_bwd', 'head_conv_bwd'):

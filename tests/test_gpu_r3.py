@@ -169,3 +169,106 @@ def test_wgrad_atomic_single_slab_matches_split_slabs(dt, case):
         assert float((gw - wref).abs().max()) <= tol, k
     for k in ((True, 5), (True, 23)):
         assert float((grads[k] - grads[(False, 5)]).abs().max()) <= 2e-5 * scale * math.sqrt(N * OH * OH / 64), k
+
+
+# (dY channels = conv Cout, dX channels = conv Cin, dX height, dX width, batch): the direct kernel's shape (64 -> 32) with whole
+# and partial tiles (8 x 64 dX pixels), and a shape only the implicit-GEMM kernels take (one merged launch)
+S2_DGRAD = [(64, 32, 80, 128, 2), (64, 32, 20, 96, 3), (64, 32, 304, 304, 1), (128, 64, 40, 48, 2)]
+
+
+@pytest.mark.parametrize('dt', ['f16', 'bf16'])
+@pytest.mark.parametrize('case', S2_DGRAD)
+def test_stride2_dgrad_one_launch_and_direct_kernel(dt, case):
+    """3x3 / stride-2 input gradient: the four parity classes as one launch of the implicit-GEMM kernels (hint 1: 4-wave,
+    6: pipelined) and, for 32 <- 64 channels, the direct kernel (hint 10) -- against float64 torch; gradient fan-in; and the
+    BatchNorm-backward sums of the producer layer in the epilogue (cy_conv_dgrad_bn_sums with stride 2) against the separate
+    reduce pass over the stored gradient."""
+    import complex_yolov4_pytorch_amd.ops as ops
+    from complex_yolov4_pytorch_amd.ops import View
+    code = ops.dtype_code(dt)
+    Cdy, Cg, H, W, N = case
+    rnd = (lambda t: t.bfloat16().float()) if dt == 'bf16' else (lambda t: t.half().float())
+    g = torch.Generator().manual_seed(Cdy + H)
+    dy = rnd(torch.randn(N, Cdy, H // 2, W // 2, generator=g))
+    w = rnd(torch.randn(Cdy, Cg, 3, 3, generator=g) / (9 * Cdy) ** 0.5)
+    gref = torch.nn.grad.conv2d_input((N, Cg, H, W), w.double(), dy.double(), 2, 1).float()
+    dyv = View.from_nchw(dy.to(DEV), code)
+    _, wd = ops.pack_weights(w.to(DEV), Cdy, Cg, code)
+    tol = dict(rtol=1.6e-2, atol=1.6e-2) if dt == 'bf16' else dict(rtol=2e-3, atol=2e-3)
+    hints = [1, 6] + ([10] if (Cdy, Cg) == (64, 32) else [])
+    n0 = ops.direct_launches()
+    outs = {}
+    for h in hints:
+        dx = View.alloc(N, H, W, Cg, code, ld=Cg + 8, zero=True)
+        ops.conv_igemm(dyv, wd, Cg, dx, 3, 2, 1, flags=ops.CONV_TRANSPOSED, tile=h)
+        torch.testing.assert_close(dx.to_nchw().cpu(), gref, **tol)
+        assert float(dx.buf.view(-1, Cg + 8)[:, Cg:].abs().max()) == 0.0          # nothing written beside the view
+        ops.conv_igemm(dyv, wd, Cg, dx, 3, 2, 1, flags=ops.CONV_TRANSPOSED | ops.CONV_ACCUM, tile=h)
+        torch.testing.assert_close(dx.to_nchw().cpu(), 2 * gref, rtol=2 * tol['rtol'], atol=2 * tol['atol'])
+        outs[h] = dx
+    if 10 in hints:
+        assert ops.direct_launches() == n0 + 2
+    # BN-backward sums of the layer whose output gradient this is
+    raw = View.alloc(N, H, W, Cg, code)
+    raw.buf.copy_(torch.randn(raw.buf.numel(), generator=g).to(raw.buf.dtype))
+    vec = torch.stack([torch.randn(Cg, generator=g) * 0.1, torch.rand(Cg, generator=g) + 0.5,
+                       torch.rand(Cg, generator=g) + 0.5, torch.randn(Cg, generator=g) * 0.2]).to(DEV)
+    M = N * H * W
+    for act in ('mish', 'leaky'):
+        a = ops.ACT[act]
+        for h in [x for x in hints if x != 1]:
+            g1 = View.alloc(N, H, W, Cg, code, zero=True)
+            ops.conv_igemm(dyv, wd, Cg, g1, 3, 2, 1, flags=ops.CONV_TRANSPOSED, tile=h)
+            part = torch.zeros(ops.bn_bwd_rows(M, Cg, code), 2, Cg, device=DEV)
+            ops.bn_act_bwd_reduce(raw, g1, vec[0], vec[1], vec[2], vec[3], a, part)
+            ref_sums = part.double().sum(0)
+            g2 = View.alloc(N, H, W, Cg, code, zero=True)
+            tbl = torch.zeros(ops.conv_stats_rows(M, Cg), 2, Cg, device=DEV)
+            ops.conv_dgrad_bn_sums(dyv, wd, Cg, g2, 3, 2, 1, raw, vec[0], vec[1], vec[2], vec[3], a, tbl,
+                                   flags=ops.CONV_TRANSPOSED, tile=h)
+            assert torch.equal(g2.buf, g1.buf), h
+            got = tbl.double().sum(0)
+            scale = ref_sums.abs().max(1, keepdim=True).values + 1e-6
+            assert float(((got - ref_sums).abs() / scale).max()) < 2e-5, (act, h)
+
+
+@pytest.mark.parametrize('dt', ['f16', 'bf16'])
+@pytest.mark.parametrize('accum', [False, True])
+@pytest.mark.parametrize('case', [(64, 64, 304, 1), (64, 128, 152, 2), (128, 64, 152, 1), (32, 64, 200, 1), (64, 32, 150, 2)])
+def test_direct1x1_dgrad_bn_sums_and_prefetched_fan_in(dt, accum, case):
+    """The 1x1 streaming kernel as an input-gradient launch (hint 10): gradient fan-in with the stored gradient prefetched, and
+    the BatchNorm-backward sums of the producer layer in its epilogue, against the 4-wave kernel followed by the reduce pass."""
+    import complex_yolov4_pytorch_amd.ops as ops
+    from complex_yolov4_pytorch_amd.ops import View
+    code = ops.dtype_code(dt)
+    Cdy, Cg, H, N = case
+    g = torch.Generator().manual_seed(Cdy * 5 + Cg + H)
+    tdt = ops.torch_dtype(code)
+    dy = View.alloc(N, H, H, Cdy, code); dy.buf.copy_(torch.randn(dy.buf.numel(), generator=g).to(tdt))
+    raw = View.alloc(N, H, H, Cg, code); raw.buf.copy_(torch.randn(raw.buf.numel(), generator=g).to(tdt))
+    w = torch.randn(Cdy, Cg, 1, 1, generator=g).to(DEV) * (1.0 / Cdy ** 0.5)
+    _, wd = ops.pack_weights(w, Cdy, Cg, code)
+    vec = torch.stack([torch.randn(Cg, generator=g) * 0.1, torch.rand(Cg, generator=g) + 0.5,
+                       torch.rand(Cg, generator=g) + 0.5, torch.randn(Cg, generator=g) * 0.2]).to(DEV)
+    base = torch.randn(raw.buf.numel(), generator=g).to(DEV).to(tdt)
+    flags = ops.CONV_TRANSPOSED | (ops.CONV_ACCUM if accum else 0)
+    M = N * H * H
+    for act in ('mish', 'leaky', 'linear'):
+        a = ops.ACT[act]
+        g1 = View.alloc(N, H, H, Cg, code); g1.buf.copy_(base)
+        ops.conv_igemm(dy, wd, Cg, g1, 1, 1, 0, flags=flags, tile=1)
+        g2 = View.alloc(N, H, H, Cg, code); g2.buf.copy_(base)
+        n0 = ops.direct_launches()
+        tbl = torch.zeros(ops.conv_stats_rows(M, Cg), 2, Cg, device=DEV)
+        ops.conv_dgrad_bn_sums(dy, wd, Cg, g2, 1, 1, 0, raw, vec[0], vec[1], vec[2], vec[3], a, tbl, flags=flags, tile=10)
+        assert ops.direct_launches() == n0 + 1
+        tol = 2e-2 if dt == 'bf16' else 3e-3
+        torch.testing.assert_close(g2.buf.float(), g1.buf.float(), rtol=tol, atol=tol)
+        part = torch.zeros(ops.bn_bwd_rows(M, Cg, code), 2, Cg, device=DEV)
+        ops.bn_act_bwd_reduce(raw, g2, vec[0], vec[1], vec[2], vec[3], a, part)      # over the gradient the fused launch stored
+        ref_sums, got = part.double().sum(0), tbl.double().sum(0)
+        scale = ref_sums.abs().max(1, keepdim=True).values + 1e-6
+        assert float(((got - ref_sums).abs() / scale).max()) < 2e-5, act
+        g3 = View.alloc(N, H, H, Cg, code); g3.buf.copy_(base)
+        ops.conv_igemm(dy, wd, Cg, g3, 1, 1, 0, flags=flags, tile=10)                # the same kernel without the sums
+        assert torch.equal(g3.buf, g2.buf)
