@@ -11,8 +11,8 @@ with `roofline` (the implicit-GEMM conv kernel family, timed with HIP events on 
 (the oracle -- a CPU restatement of the reference -- timed on this host's cores on a bounded sample).
 infer32 (configs[3]): model.eval()(imgs) + post_processing_v2 (rotated merge-NMS on the device), batch 32.
 train1024 (configs[4]): the train step at 1024x1024, batch 8.
-The default single-GPU run also measures the other two configurations briefly and reports them under `other_configs`,
-so the one driver line carries configs[1], [3] and [4].
+The default single-GPU run also measures the other configurations briefly -- each in a fresh process of this same script -- and
+reports them under `other_configs`, so the one driver line carries configs[1], [3], [4] and configs[2]'s per-GPU work.
 """
 import argparse
 import json
@@ -80,39 +80,54 @@ def usable_cores(cap=32):
 
 
 def kernel_sources_sha():
-    """sha256 over the HIP sources the measured kernels are built from (what a committed PMC figure is valid for)."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'complex-yolov4-pytorch_amd', 'csrc', '*.h*'))):
-        with open(f, 'rb') as fh:
-            h.update(os.path.basename(f).encode() + b'\0' + fh.read())
-    return h.hexdigest()[:16]
+    """sha256 over the HIP sources the measured kernels are built from (what a committed PMC figure / tune table is valid for)."""
+    from complex_yolov4_pytorch_amd import tune
+    return tune.sources_sha()
+
+
+PMC_FILE = 'profiles/r03_pmc_hbm_traffic.json'
 
 
 def pmc_traffic(kernel, a):
-    """HBM bytes per launch of the kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    """HBM bytes PER STEP of the kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
     separate runs of this same command; FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
     cannot be read from inside the process, so this is the recorded figure for the default workload -- and only while the
     kernel sources are the ones it was measured on (tools/pmc_traffic.sh stamps their hash and the git head): a stale
-    file yields null, never an old number."""
+    file yields null, never an old number.  The caller divides by ITS launch count, so that `traffic` and the algorithmic
+    bytes of the roofline object sit on one basis (round 2 mixed rocprof dispatches with bench brackets)."""
     if (a.batch, a.size, a.dtype, a.config) != (16, 608, 'f16', 'train608'):
         return None
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
+    path = os.path.join(ROOT, PMC_FILE)
     try:
         with open(path) as f:
             doc = json.load(f)
         if doc.get('kernel_sources_sha') != kernel_sources_sha():
-            return dict(bytes_per_launch=None, stale=True, measured_on=doc.get('kernel_sources_sha'), now=kernel_sources_sha(),
-                        source='profiles/r02_pmc_hbm_traffic.json')
+            return dict(bytes_per_step=None, stale=True, measured_on=doc.get('kernel_sources_sha'), now=kernel_sources_sha(),
+                        source=PMC_FILE)
         d = doc[kernel]
-        return dict(bytes_per_launch=round(d['fetch_bytes_per_launch_corrected'] + d['write_bytes_per_launch']),
-                    fetch=round(d['fetch_bytes_per_launch_corrected']), write=round(d['write_bytes_per_launch']),
-                    launches_counted=d.get('launches'), unit='bytes', git_head=doc.get('git_head'),
-                    kernel_sources_sha=doc.get('kernel_sources_sha'),
-                    source='profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.sh)')
+        steps = float(doc.get('steps_counted', 1))
+        fetch = d['fetch_bytes_per_launch_corrected'] * d['launches'] / steps
+        write = d['write_bytes_per_launch'] * d['launches'] / steps
+        whole = sum((v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch']) * v['launches'] / steps
+                    for v in doc.values() if isinstance(v, dict) and 'launches' in v)
+        return dict(bytes_per_step=round(fetch + write), fetch_per_step=round(fetch), write_per_step=round(write),
+                    dispatches_per_step=round(d['launches'] / steps, 1), whole_step_bytes=round(whole), unit='bytes',
+                    git_head=doc.get('git_head'), kernel_sources_sha=doc.get('kernel_sources_sha'),
+                    source=PMC_FILE + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.sh)')
     except (OSError, KeyError, ValueError):
         return None
+
+
+def step_flops(model):
+    """Algorithmic FLOPs of one train step of the model's engines: 2 M Cout k^2 Cin per conv with the REAL channel counts, once
+    for the forward, the input gradient (not for the first layer) and the weight gradient."""
+    total = 0.0
+    for e in model._engines.values():
+        if e.training:
+            for rec in e.plan.convs:
+                fl = e._conv_work(rec)[0]
+                total += fl * (2.0 if rec['first'] else 3.0)
+    return total
 
 
 def cpu_baseline(batch, size, seconds_budget=20.0):
@@ -175,8 +190,9 @@ def measure_inference(dev, batch, size, dtype, steps, warmup):
     model.release_engines()
     return dict(metric='BEV images/s (%dx%d) inference + rotated NMS' % (size, size), value=round(batch / dt, 2), unit='images/s',
                 ms_per_step=round(1e3 * dt, 3), steps=steps, dtype=dtype,
-                workload='complex_yolov4.cfg model.eval() forward, batch %d, %dx%d + post_processing_v2 on the device '
-                         '(256 candidates/image)' % (batch, size, size))
+                workload='complex_yolov4.cfg model.eval() forward, batch %d, %dx%d (outputs stay on the device: no 29 MB D2H) + '
+                         'post_processing_v2 on the device over SYNTHETIC predictions with 256 candidates/image (random-init weights '
+                         'yield no confident boxes), both stages in every timed step' % (batch, size, size))
 
 
 def batch_source(dev, batch, size, mosaic, seed=0):
@@ -238,6 +254,20 @@ def measure_train(dev, batch, size, dtype, steps, warmup, mosaic=False):
                 ms_per_step=round(1e3 * dt, 3), steps=steps, dtype=dtype, loss_final=round(final, 4),
                 workload='complex_yolov4.cfg train step (%sfwd + rotated-GIoU loss + bwd + Adam), batch %d, %dx%d'
                          % ('device mosaic of four %dx%d maps per sample + ' % (size // 2, size // 2) if mosaic else '', batch, size, size))
+
+
+def measure_other(config, dtype, steps, warmup):
+    """One of the other configurations, measured by this same script in a fresh process (its ONE JSON line, reduced)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', config, '--dtype', dtype, '--steps', str(steps), '--warmup', str(warmup),
+           '--no-extra', '--no-cpu-baseline', '--no-roofline']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return dict(metric=d['metric'], value=d['value'], unit=d['unit'], ms_per_step=d['ms_per_step'], steps=d['steps'], dtype=d['dtype'],
+                    workload=d['config']['workload'], loss_final=d['config'].get('loss_final'), process='fresh')
+    except Exception as e:      # noqa: BLE001 -- the headline line must still be printed
+        return dict(error='%s: %r' % (config, e))
 
 
 def main():
@@ -374,10 +404,14 @@ def main():
             ach = ig['flops'] / (ig['ms_raw'] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[a.dtype]
             tr = pmc_traffic('igemm', a)
+            brackets = ig['launches'] // 2                     # launches of the family per step as the engine issues them
+            tr_launch = round(tr['bytes_per_step'] / brackets) if tr and tr.get('bytes_per_step') else None
             roofline = dict(bound='mfma', kernel='implicit-GEMM conv kernels (forward + dgrad launches: igemm_fast_kernel / igemm_kernel '
                                                  '4-wave tiles, igemm_pipe_kernel 8-wave tiles, direct3x3 / direct1x1 streaming kernels for the small-Cin and big-grid 1x1 layers, chosen per layer; dgrad launches that also accumulate BatchNorm-backward sums included)',
                             achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                            traffic=(tr or {}).get('bytes_per_launch'), traffic_detail=tr,
+                            traffic=tr_launch, traffic_detail=tr,
+                            traffic_over_algorithmic=round(tr_launch / (ig['bytes'] / ig['launches']), 3) if tr_launch else None,
+                            algorithmic_bytes_per_step=round(ig['bytes'] / 2),
                             launches_per_step=ig['launches'] // 2, avg_launch_us=round(1e3 * ig['ms_raw'] / ig['launches'], 2),
                             hbm_gbs_algorithmic=round(ig['bytes'] / (ig['ms_raw'] * 1e-3) / 1e9, 1),
                             algorithmic_bytes_per_launch=round(ig['bytes'] / ig['launches']),
@@ -396,6 +430,12 @@ def main():
                            achieved=round(f['flops'] / (f['ms_raw'] * 1e-3) / 1e12, 2), unit='TFLOP/s')
                 for name, f in (('conv_only', plain), ('dgrad_with_bn_backward_sums', fused)) if f}
             roofline['by_bound'] = by_bound   # launches above the ridge point against the MFMA peak, the rest against HBM
+            # BASELINE's "MFMA util %": the WHOLE train step's algorithmic FLOPs (forward + input gradient + weight gradient of
+            # every conv) over the timed region's wall clock, against the dense MFMA peak
+            sf = step_flops(model)
+            roofline['step_tflops'] = round(sf / (elapsed / a.steps) / 1e12, 1)
+            roofline['step_frac'] = round(sf / (elapsed / a.steps) / (peak * 1e12), 4)
+            roofline['step_gflop'] = round(sf / 1e9, 1)
     if world > 1:
         dist.barrier()
 
@@ -404,15 +444,20 @@ def main():
         cpu = None
         others = None
         if world == 1 and a.config == 'train608' and not a.no_extra:
-            # free this configuration's 17 GB of storages, then measure configs[3] and configs[4] briefly
+            # free this configuration's 17 GB of storages, then measure configs[3], configs[4], the bf16 mode and configs[2]'s
+            # per-GPU work briefly -- each in a FRESH PROCESS.  In one process the later configurations ran on whatever the
+            # earlier ones left behind: tools/order_probe.py (profiles/r03_order_probe.txt) shows train1216 at 234 images/s
+            # as the first 54 GB allocation of a process, 200 after a 17 GB configuration was allocated and freed in between,
+            # 236 again on the next try, with train608 and the clocks unchanged throughout -- the state of the device's
+            # memory mappings after a free / re-allocate, not the kernels (round 2's "15 % slower inside the default run").
             model.release_engines()
             del opt
             torch.cuda.empty_cache()
-            others = {'infer32': measure_inference(dev, 32, 608, a.dtype, 8, 3),
-                      'train1024': measure_train(dev, 8, 1024, a.dtype, 5, 2)}
+            others = {'infer32': measure_other('infer32', a.dtype, 8, 3),
+                      'train1024': measure_other('train1024', a.dtype, 5, 2)}
             if a.dtype == 'f16':
-                others['train608_bf16'] = measure_train(dev, 16, 608, 'bf16', 6, 3)
-            others['train1216_mosaic'] = measure_train(dev, 16, 1216, a.dtype, 4, 3, mosaic=True)
+                others['train608_bf16'] = measure_other('train608', 'bf16', 6, 3)
+            others['train1216_mosaic'] = measure_other('train1216', a.dtype, 4, 3)
         if not a.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(2, a.size)
         imgs = world * a.batch * a.steps

@@ -11,14 +11,19 @@ LIB = os.path.join(CSRC, 'libcyolo_hip.so')
 SOURCES = ['conv_igemm.hip', 'conv_pipe.hip', 'conv_direct.hip', 'conv_wgrad.hip', 'elementwise.hip', 'yolo_head.hip', 'riou_nms.hip', 'bev.hip']
 HEADERS = ['common.hpp', 'igemm_common.hpp', 'geometry.hpp', os.path.join(INCLUDE, 'cyolo_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC, '-Wno-unused-value']
-# Per-file flags.  yolo_head.hip: the per-target kernels (assign, pairs) index small polygon arrays dynamically; with the default
-# promote-alloca budget they lived in scratch memory (368 / 880 bytes per lane) and were the only kernels of the step whose
-# results changed when another kernel ran beside them (tools/head_race_probe.py).  With this budget (and their 64-thread
-# launch bounds) every array is a register vector: ScratchSize 0.
-EXTRA_FLAGS = {'yolo_head.hip': ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=1024', '-Rpass-analysis=kernel-resource-usage']}
-# kernels that must come out of the compiler without a private segment (checked on every compile of their file, see
-# check_scratch): a different hipcc or an edit of geometry.hpp can bring the spill back silently
-NO_SCRATCH = {'yolo_head.hip': ('assign_kernel', 'pairs_kernel', 'giou_grad_kernel')}
+# Per-file flags.  yolo_head.hip / riou_nms.hip: the per-target / per-pair kernels index small polygon arrays dynamically; with the
+# default promote-alloca budget they lived in scratch memory (368 / 880 bytes per lane) and assign / pairs were the only kernels of
+# the step whose results changed when another kernel ran beside them (tools/head_race_probe.py).  With this budget (and their
+# 64-thread launch bounds) every array is a register vector: ScratchSize 0.
+_ALLOCA = ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=1024']
+_REMARKS = ['-Rpass-analysis=kernel-resource-usage']
+EXTRA_FLAGS = {src: _REMARKS + (_ALLOCA if src in ('yolo_head.hip', 'riou_nms.hip') else []) for src in SOURCES}
+# NO kernel of the library may come out of the compiler with a private segment (scratch): checked on every compile of every
+# file (check_scratch).  Round 2 found the head kernels' results to depend on what ran beside them while they spilled; round 3
+# found two conv instantiations that had quietly acquired spills (a 384 x 128 direct-store epilogue, 196 bytes per lane) while
+# hunting a 1-in-10^4 gradient difference of the deterministic mode.  A different hipcc or a small edit can bring a spill
+# back silently -- with this check it fails the build instead.  '*' = every kernel of the file.
+NO_SCRATCH = {src: ('*',) for src in SOURCES}
 RESOURCES = os.path.join(CSRC, 'kernel_resources.json')
 
 
@@ -53,13 +58,13 @@ def check_scratch(src, text):
     with open(RESOURCES, 'w') as f:
         json.dump(doc, f, indent=1, sort_keys=True)
     wanted = NO_SCRATCH.get(src, ())
-    seen = {w: [k for k in res if w in k] for w in wanted}
+    seen = {w: [k for k in res if w == '*' or w in k] for w in wanted}
     missing = [w for w, ks in seen.items() if not ks]
     if missing:
         raise RuntimeError('%s: no resource-usage remark for %s (compiler output format changed?)' % (src, missing))
     bad = {k: res[k].get('scratch') for ks in seen.values() for k in ks if res[k].get('scratch', -1) != 0}
     if bad:
-        raise RuntimeError('%s: per-target kernels must have ScratchSize 0 (side-stream precondition, see yolo_head.hip): %s' % (src, bad))
+        raise RuntimeError('%s: kernels must have ScratchSize 0 (no private segment anywhere in the library, see build.py): %s' % (src, bad))
     return res
 
 

@@ -330,9 +330,13 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
             if (m0 + px < M) pre[it] = *reinterpret_cast<const u32x4*>(p.g + (size_t)(m0 + px) * pixg + c * 16);
         }
     };
-    if ((int)blockIdx.x < ntiles) issue(blockIdx.x);
+    // (the 128-channel EXTRA instantiation has no registers to spare for the next tile's rows: it fetches each tile when it
+    // gets there and leaves the latency to the second block of the CU)
+    constexpr bool PRE = !(EXTRA && COUT > 64);
+    if (PRE && (int)blockIdx.x < ntiles) issue(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long m0 = (long)tile * C::TP;
+        if (!PRE) issue(tile);
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < C::NIT; ++it) {
@@ -340,7 +344,7 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
             *reinterpret_cast<u32x4*>(patch + px * C::PXB + ((c ^ (px & (C::CPP - 1))) << 4)) = pre[it];
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        if (PRE && tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
         // epilogue operands (pre-BN tensor for the sums, stored gradient for a fan-in launch) of one (segment, channel pass) at a
         // time: the first before the MFMAs, each next one while the previous is being stored
         tx8 rawv[EXTRA ? NSI : 1], oldv[EXTRA ? NSI : 1];
@@ -539,7 +543,9 @@ int pw_launch_x(const IgemmParams& p, hipStream_t s) {
 
 template <typename T, int CIN, int COUT, int SPW>
 int pw_launch(const IgemmParams& p, hipStream_t s) {
-    if (p.flags & (CY_CONV_ACCUM | CY_CONV_BNBWD_SUMS)) return pw_launch_x<T, CIN, COUT, SPW, true>(p, s);
+    // (the EXTRA instantiations run one 32-pixel segment per wave: half the accumulators, room for the prefetched operands --
+    // no kernel of the train step may spill to scratch memory, see build.py)
+    if (p.flags & (CY_CONV_ACCUM | CY_CONV_BNBWD_SUMS)) return pw_launch_x<T, CIN, COUT, 1, true>(p, s);
     return pw_launch_x<T, CIN, COUT, SPW, false>(p, s);
 }
 

@@ -542,11 +542,15 @@ int pipe_launch(const IgemmParams& p0, hipStream_t s) {
 // 1 direct stores from the MFMA layout, 2 two-stage ring, 3 four loader + eight compute waves.
 template <typename T>
 int pipe_dispatch(const IgemmParams& p, int cap, int bn, int variant, hipStream_t s) {
+    // (the direct-store epilogue of a 384 x 128 tile needs more than 256 VGPRs -- 196 bytes of scratch per lane in round 2 -- and
+    // no kernel of the train step may use scratch memory, see build.py: that capacity always stores through LDS)
 #define CY_PIPE(BM_, BN_, WN_, NST_)                                                           \
     if (cap == BM_ && bn == BN_) {                                                             \
         if (p.flags & CY_CONV_BNBWD_SUMS) {                                                                    \
             if (variant == 1) return CY_ERR_ARG;   /* the sums live in the LDS-transposed store path */          \
-        } else if (variant == 1 || (p.flags & CY_CONV_ACCUM)) return pipe_launch<T, BM_, BN_, WN_, NST_, false>(p, s); \
+        } else if constexpr (!(BM_ == 384 && BN_ == 128)) {                                                     \
+            if (variant == 1 || (p.flags & CY_CONV_ACCUM)) return pipe_launch<T, BM_, BN_, WN_, NST_, false>(p, s); \
+        }                                                                                                      \
         if (variant == 2) return pipe_launch<T, BM_, BN_, WN_, 2, true>(p, s);                                \
         if constexpr (NST_ == 3) { if (variant == 3) return pipe_launch<T, BM_, BN_, WN_, 3, true, 4>(p, s); } \
         return pipe_launch<T, BM_, BN_, WN_, NST_, true>(p, s);                                               \

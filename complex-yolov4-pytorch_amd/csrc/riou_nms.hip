@@ -7,20 +7,23 @@
 
 namespace {
 
-__global__ void riou_pairs_kernel(const float* __restrict__ pred, const float* __restrict__ target, int n, int giou,
-                                  float* ious, float* terms, float* gpred) {
+// (64-thread launch bounds, the loss variant a template parameter and build.py's promote-alloca budget keep the polygon arrays
+// of these per-pair kernels in registers, as for yolo_head.hip's: no kernel of the library uses scratch memory)
+template <bool GIOU>
+__global__ void __launch_bounds__(64) riou_pairs_kernel(const float* __restrict__ pred, const float* __restrict__ target, int n,
+                                                        float* ious, float* terms, float* gpred) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     float p[6], t[6];
     for (int i = 0; i < 6; ++i) { p[i] = pred[(long)k * 6 + i]; t[i] = target[(long)k * 6 + i]; }
-    const geom::PairOut o = geom::pair_term(p, t, giou != 0);
+    const geom::PairOut o = geom::pair_term_t<GIOU>(p, t);
     ious[k] = o.iou;
     terms[k] = o.term;
     if (gpred)
         for (int i = 0; i < 6; ++i) gpred[(long)k * 6 + i] = o.g[i];
 }
 
-__global__ void riou_anchors_kernel(const float* __restrict__ anc, int nA, const float* __restrict__ tg, int nT,
+__global__ void __launch_bounds__(64) riou_anchors_kernel(const float* __restrict__ anc, int nA, const float* __restrict__ tg, int nT,
                                     float* ious) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nA * nT) return;
@@ -53,7 +56,7 @@ __device__ __forceinline__ float box_iou(const BoxGeo& a, const BoxGeo& b, float
     return geom::iou_from_inter(geom::quad_inter_f64(a.cx, a.cy, b.cx, b.cy), a.area, b.area, eps);
 }
 
-__global__ void riou_matrix_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb, float eps,
+__global__ void __launch_bounds__(64) riou_matrix_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb, float eps,
                                    float* iou) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)na * nb) return;
@@ -292,8 +295,8 @@ extern "C" int cy_riou_pairs(const float* pred, const float* target, int n, int 
     CY_ENTER();
     if (n < 0 || (n > 0 && (!pred || !target || !ious || !terms))) return CY_ERR_ARG;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(riou_pairs_kernel, dim3((n + 63) / 64), dim3(64), 0, cy_s(s), pred, target, n, giou, ious, terms,
-                       gpred);
+    if (giou) hipLaunchKernelGGL(riou_pairs_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, cy_s(s), pred, target, n, ious, terms, gpred);
+    else hipLaunchKernelGGL(riou_pairs_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, cy_s(s), pred, target, n, ious, terms, gpred);
     CY_LAUNCH_CHECK();
     return 0;
 }
@@ -314,8 +317,7 @@ extern "C" int cy_riou_matrix(const float* a, int na, const float* b, int nb, fl
     if (na < 0 || nb < 0 || (na > 0 && nb > 0 && (!a || !b || !iou))) return CY_ERR_ARG;
     if (na == 0 || nb == 0) return 0;
     const long total = (long)na * nb;
-    hipLaunchKernelGGL(riou_matrix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, cy_s(s), a, na, b, nb,
-                       eps, iou);
+    hipLaunchKernelGGL(riou_matrix_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, cy_s(s), a, na, b, nb, eps, iou);
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -1,21 +1,21 @@
 #!/bin/bash
 # HBM traffic per kernel family for the bench workload: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
-# passes as MI355X_MICROARCH.md prescribes), aggregated per launch.  FETCH_SIZE is doubled (gfx950 reports 64 B per
-# 128-B request for wide coalesced reads).  The wgrad split autotuner is off in these passes (its timing launches would
-# count as wgrad launches).  Writes gpurun_out/pmc_hbm_traffic.json; copy it to profiles/ to commit.
+# passes as MI355X_MICROARCH.md prescribes), aggregated per launch (x launches / steps_counted = per step).  FETCH_SIZE is doubled (gfx950
+# reports 64 B per 128-B request for wide coalesced reads).  Only dispatches after the second optimizer launch are counted, so
+# one-time tuning launches (none when the persisted tune table is valid) stay out.  Writes gpurun_out/pmc_hbm_traffic.json; copy it to profiles/ to commit.
 export TMPDIR=/tmp
 root=$(pwd)
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$root/gpurun_out/pmc_$c
   rm -rf $out
-  (cd /tmp && CY_WGRAD_AUTOTUNE=0 rocprofv3 --pmc $c --output-format csv -d $out -- python $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra > $root/gpurun_out/pmc_$c.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $c --output-format csv -d $out -- python $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra > $root/gpurun_out/pmc_$c.log 2>&1)
 done
 python - "$root/gpurun_out" "$root" <<'PY'
 import csv, glob, json, os, sys, collections
 root = sys.argv[1]
 sys.path.insert(0, sys.argv[2])
 import bench
-FAM = [('igemm', ('igemm_fast_kernel', 'igemm_kernel', 'igemm_pipe_kernel', 'direct3x3_kernel', 'direct1x1_kernel')), ('wgrad', ('wgrad_dma_kernel', 'wgrad_kernel')),
+FAM = [('igemm', ('igemm_fast_kernel', 'igemm_kernel', 'igemm_pipe_kernel', 'direct3x3_kernel', 'direct1x1_kernel', 'direct_s2dgrad_kernel')), ('wgrad', ('wgrad_dma_kernel', 'wgrad_kernel')),
        ('wgrad_reduce', ('wgrad_reduce',)), ('bn_act_fwd', ('bn_act_fwd',)), ('bn_bwd_reduce', ('bn_bwd_reduce',)),
        ('bn_bwd_apply', ('bn_bwd_apply',)), ('bn_bwd_finalize', ('bn_bwd_finalize',)), ('bn_finalize', ('bn_finalize',)),
        ('pack_weights', ('pack_weights',)), ('adam', ('adam_multi',))]
@@ -45,7 +45,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         agg[k]['launches'] = max(agg[k]['launches'], v)
 # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-units of 1024? -> the counters are in KB (1 KB = 1024 B) per the tool's derived metric
 out = {'steps_counted': STEADY, 'kernel_sources_sha': bench.kernel_sources_sha(), 'git_head': os.environ.get('GIT_HEAD', 'unknown'),
-       'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra (CY_WGRAD_AUTOTUNE=0)'}
+       'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra'}
 for k, v in sorted(agg.items()):
     L = max(1, v['launches'])
     out[k] = dict(launches=v['launches'], fetch_bytes_per_launch_corrected=2.0 * 1024.0 * v['FETCH_SIZE'] / L,
