@@ -14,7 +14,7 @@ HEADER = os.path.join(_HERE, '..', 'include', 'cyolo_hip.h')
 LIBPATH = os.path.join(_HERE, 'csrc', 'libcyolo_hip.so')
 
 _SCALARS = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'cy_stream_t': ctypes.c_void_p,
-            'int32_t': ctypes.c_int32}
+            'int32_t': ctypes.c_int32, 'uint32_t': ctypes.c_uint32}
 
 
 class CyoloError(RuntimeError):

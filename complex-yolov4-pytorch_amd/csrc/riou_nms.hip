@@ -12,11 +12,12 @@ namespace {
 template <bool GIOU>
 __global__ void __launch_bounds__(64) riou_pairs_kernel(const float* __restrict__ pred, const float* __restrict__ target, int n,
                                                         float* ious, float* terms, float* gpred) {
+    CY_GEOM_POOL(P);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     float p[6], t[6];
     for (int i = 0; i < 6; ++i) { p[i] = pred[(long)k * 6 + i]; t[i] = target[(long)k * 6 + i]; }
-    const geom::PairOut o = geom::pair_term_t<GIOU>(p, t);
+    const geom::PairOut o = geom::pair_term_t<GIOU>(P, p, t);
     ious[k] = o.iou;
     terms[k] = o.term;
     if (gpred)
@@ -25,6 +26,7 @@ __global__ void __launch_bounds__(64) riou_pairs_kernel(const float* __restrict_
 
 __global__ void __launch_bounds__(64) riou_anchors_kernel(const float* __restrict__ anc, int nA, const float* __restrict__ tg, int nT,
                                     float* ious) {
+    CY_GEOM_POOL(P);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nA * nT) return;
     const int a = idx / nT, t = idx - a * nT;
@@ -33,7 +35,7 @@ __global__ void __launch_bounds__(64) riou_anchors_kernel(const float* __restric
     const float* T = tg + (long)t * 4;
     geom::corners(100.f, 100.f, A[0], A[1], atan2f(A[2], A[3]), acx, acy);
     geom::corners(100.f, 100.f, T[0], T[1], atan2f(T[2], T[3]), tcx, tcy);
-    ious[idx] = geom::iou_from_inter(geom::quad_inter_f64(acx, acy, tcx, tcy), A[0] * A[1], T[0] * T[1], 1e-16f);
+    ious[idx] = geom::iou_from_inter(geom::quad_inter_f64(P, acx, acy, tcx, tcy), A[0] * A[1], T[0] * T[1], 1e-16f);
 }
 
 struct BoxGeo {
@@ -51,18 +53,19 @@ __device__ __forceinline__ bool far_apart(const BoxGeo& a, const BoxGeo& b) {
     const float dx = a.x - b.x, dy = a.y - b.y, r = (a.rad + b.rad) * 1.01f + 1e-3f;
     return dx * dx + dy * dy > r * r;
 }
-__device__ __forceinline__ float box_iou(const BoxGeo& a, const BoxGeo& b, float eps) {
+__device__ __forceinline__ float box_iou(const geom::Pool& P, const BoxGeo& a, const BoxGeo& b, float eps) {
     if (far_apart(a, b)) return 0.f;
-    return geom::iou_from_inter(geom::quad_inter_f64(a.cx, a.cy, b.cx, b.cy), a.area, b.area, eps);
+    return geom::iou_from_inter(geom::quad_inter_f64(P, a.cx, a.cy, b.cx, b.cy), a.area, b.area, eps);
 }
 
 __global__ void __launch_bounds__(64) riou_matrix_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb, float eps,
                                    float* iou) {
+    CY_GEOM_POOL(P);
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)na * nb) return;
     const int i = (int)(idx / nb), j = (int)(idx - (long)i * nb);
     const BoxGeo A = box_geo(a + (long)i * 6), Bx = box_geo(b + (long)j * 6);
-    iou[idx] = geom::iou_from_inter(geom::quad_inter_f64(A.cx, A.cy, Bx.cx, Bx.cy), A.area, Bx.area, eps);
+    iou[idx] = geom::iou_from_inter(geom::quad_inter_f64(P, A.cx, A.cy, Bx.cx, Bx.cy), A.area, Bx.area, eps);
 }
 
 // ---- ranking by counting: rank_i = #{j : key_j before key_i}, keys (score desc, index asc) ---------
@@ -137,6 +140,7 @@ __global__ void greedy_geo_kernel(const float* __restrict__ boxes, int K, NmsWor
 template <bool SAME_CLASS>
 __global__ void __launch_bounds__(64) mask_kernel(NmsWork w, int K, const int* __restrict__ counts, int count_fixed,
                                                   float thresh, float eps) {
+    CY_GEOM_POOL(P);
     const int b = blockIdx.z, i = blockIdx.x, word = blockIdx.y, lane = threadIdx.x;
     const int cnt = counts ? min(counts[b], K) : count_fixed;
     if (i >= cnt || word * 64 >= cnt) return;
@@ -155,7 +159,7 @@ __global__ void __launch_bounds__(64) mask_kernel(NmsWork w, int K, const int* _
             const float* gj = w.geo + ((long)b * K + j) * 12;
             bool ok = true;
             if (SAME_CLASS) ok = w.attr[((long)b * K + i) * 10 + 8] == w.attr[((long)b * K + j) * 10 + 8];
-            if (ok) hit = box_iou(load_geo(gi), load_geo(gj), eps) > thresh;
+            if (ok) hit = box_iou(P, load_geo(gi), load_geo(gj), eps) > thresh;
         }
     }
     const unsigned long long m = __ballot(hit);

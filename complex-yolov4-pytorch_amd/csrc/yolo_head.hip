@@ -27,6 +27,7 @@ struct Work {
     int* cnt;       // [C_COUNT]
     int* ti;        // [nT][4]  b, best anchor, gj, gi  (b = -1: rejected)
     float* tf;      // [nT][8]  iou, term, g[6]
+    float* part;    // [2][nT][12]  the two halves of a pair term: intersection (inter, dIx[4], dIy[4]) / hull (carea, sg, dy[4], dx[4], on)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -51,46 +52,74 @@ __global__ void decode_kernel(const float* __restrict__ logits, int B, int G, in
     }
 }
 
+// Wave-cooperative target assignment (reference yolo_layer.py:69-142 with iou_rotated_boxes_utils.py:64-96 per anchor): LPT = 4
+// lanes per target, lane `sub` clips the target against anchors sub, sub + 4, ... (the float64 convex clip, the long pole of
+// the head: three of them in series per target were 57-62 us of pure latency per launch), then the best anchor is an argmax
+// over the 4 lanes by __shfl_xor with the reference's tie rule (the FIRST maximum in anchor order).  Every lane raises the
+// "not no-object" flags of its own anchors; lane 0 of the target records the assignment and claims the cell.
 // (64-thread blocks, stated to the compiler: with the register budget of a single wave per SIMD the polygon arrays of the
-// two per-target kernels are promoted to registers.  They were the only kernels of the step with scratch memory -- 368 and
-// 880 bytes per lane -- and the ones whose results changed when another kernel ran beside them: tools/head_race_probe.py)
+// per-target kernels are promoted to registers.  They were the only kernels of the step with scratch memory -- 368 and 880
+// bytes per lane -- and the ones whose results changed when another kernel ran beside them: tools/head_race_probe.py)
+constexpr int LPT = 4;
 __global__ void __launch_bounds__(64) assign_kernel(const float* __restrict__ targets, int nT, int B, int G, int A, Anchors an,
                               float ignore_thresh, Work w) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nT) return;
-    const float* t = targets + (long)k * 8;
+    CY_GEOM_POOL(P);
+    const int lane = threadIdx.x, sub = lane & (LPT - 1);
+    const int k = blockIdx.x * (64 / LPT) + (lane >> 2);
+    const bool live = k < nT;
+    const float* t = targets + (long)(live ? k : 0) * 8;
     const int b = (int)t[0], label = (int)t[1];
     const float gf = (float)G;
     const float x = t[2] * gf, y = t[3] * gf, tw = t[4] * gf, tl = t[5] * gf;
     const int gi = (int)x, gj = (int)y;
-    if (b < 0 || b >= B || gi < 0 || gi >= G || gj < 0 || gj >= G || label < 0 || label > 22) {
-        w.ti[k * 4] = -1;
-        atomicAdd(&w.cnt[C_ERR], 1);
-        return;
-    }
+    const bool bad = b < 0 || b >= B || gi < 0 || gi >= G || gj < 0 || gj >= G || label < 0 || label > 22;
     float tcx[4], tcy[4], acx[4], acy[4];
     geom::corners(100.f, 100.f, tw, tl, atan2f(t[6], t[7]), tcx, tcy);
     const float tarea = tw * tl;
     float best_iou = -1.f;
     int best = 0;
-    float ious[MAXA];
-    for (int a = 0; a < A; ++a) {
+    float ious[MAXA / LPT];
+#pragma unroll
+    for (int i = 0; i < MAXA / LPT; ++i) {
+        const int a = sub + LPT * i;
+        ious[i] = -2.f;
+        if (a >= A) continue;          // (wave-uniform per i only when A is a multiple of LPT; the clip below is per lane anyway)
         geom::corners(100.f, 100.f, an.w[a], an.h[a], atan2f(an.im[a], an.re[a]), acx, acy);
-        const double inter = geom::quad_inter_f64(acx, acy, tcx, tcy);
-        ious[a] = geom::iou_from_inter(inter, an.w[a] * an.h[a], tarea, 1e-16f);
-        if (ious[a] > best_iou) { best_iou = ious[a]; best = a; }
+        const double inter = geom::quad_inter_f64(P, acx, acy, tcx, tcy);
+        ious[i] = geom::iou_from_inter(inter, an.w[a] * an.h[a], tarea, 1e-16f);
+        if (ious[i] > best_iou) { best_iou = ious[i]; best = a; }
     }
-    w.ti[k * 4 + 0] = b; w.ti[k * 4 + 1] = best; w.ti[k * 4 + 2] = gj; w.ti[k * 4 + 3] = gi;
-    for (int a = 0; a < A; ++a) {
-        if (a != best && !(ious[a] > ignore_thresh)) continue;
+    // argmax over the target's lanes: larger IoU wins, equal IoUs keep the lower anchor (= the reference's first maximum)
+#pragma unroll
+    for (int m = 1; m < LPT; m <<= 1) {
+        const float oi = __shfl_xor(best_iou, m);
+        const int oa = __shfl_xor(best, m);
+        if (oi > best_iou || (oi == best_iou && oa < best)) { best_iou = oi; best = oa; }
+    }
+    if (!live) return;
+    if (bad) {
+        if (sub == 0) {
+            w.ti[k * 4] = -1;
+            atomicAdd(&w.cnt[C_ERR], 1);
+        }
+        return;
+    }
+    if (sub == 0) { w.ti[k * 4 + 0] = b; w.ti[k * 4 + 1] = best; w.ti[k * 4 + 2] = gj; w.ti[k * 4 + 3] = gi; }
+#pragma unroll
+    for (int i = 0; i < MAXA / LPT; ++i) {
+        const int a = sub + LPT * i;
+        if (a >= A) continue;
+        if (a != best && !(ious[i] > ignore_thresh)) continue;
         const int cell = ((b * A + a) * G + gj) * G + gi;
         const int old = atomicOr(&w.flags[cell], 1);
         if (!(old & 1)) atomicAdd(&w.cnt[C_NCLEARED], 1);
     }
-    const int cell = ((b * A + best) * G + gj) * G + gi;
-    atomicOr(&w.flags[cell], 1 << (8 + label));
-    const int old = atomicMax(&w.owner[cell], k + 1);
-    if (old == 0) atomicAdd(&w.cnt[C_NOBJ], 1);
+    if (sub == 0) {
+        const int cell = ((b * A + best) * G + gj) * G + gi;
+        atomicOr(&w.flags[cell], 1 << (8 + label));
+        const int old = atomicMax(&w.owner[cell], k + 1);
+        if (old == 0) atomicAdd(&w.cnt[C_NOBJ], 1);
+    }
 }
 
 __device__ __forceinline__ void decode_box(const float* t, int gi, int gj, float aw, float ah, float* box) {
@@ -102,10 +131,50 @@ __device__ __forceinline__ void decode_box(const float* t, int gi, int gj, float
     box[5] = t[5];
 }
 
+// Prediction-vs-target IoU / GIoU term and its gradient (reference iou_rotated_boxes_utils.py:98-142).  The term has two
+// independent halves (geometry.hpp): the reference's float32 polygon clip with the intersection area, and the 8-point convex
+// hull (GIoU's enclosing area).  They run as two halves of ONE grid -- blocks [0, nb) the clips, blocks [nb, 2 nb) the hulls,
+// one lane per target each, every wave executing a single code path (two lanes of a wave would run the halves one after the
+// other: divergence serialises them) -- and leave their results in the workspace; pairs_finish_kernel joins them.
 template <bool GIOU>
 __global__ void __launch_bounds__(64) pairs_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
-                                                   int G, int A, int C, Anchors an, Work w) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+                                                   int G, int A, int C, Anchors an, Work w, int nb) {
+    CY_GEOM_POOL(P);
+    const int part = (int)blockIdx.x >= nb ? 1 : 0;
+    const int k = ((int)blockIdx.x - part * nb) * 64 + (int)threadIdx.x;
+    if (k >= nT) return;
+    const int b = w.ti[k * 4];
+    if (b < 0) return;
+    const int a = w.ti[k * 4 + 1], gj = w.ti[k * 4 + 2], gi = w.ti[k * 4 + 3];
+    const int NCH = 7 + C;
+    const float* lg = logits + ((long)(b * G + gj) * G + gi) * (A * NCH) + a * NCH;
+    float pb[6], tb[6];
+    decode_box(lg, gi, gj, an.w[a], an.h[a], pb);
+    const float* t = targets + (long)k * 8;
+    const float gf = (float)G;
+    tb[0] = t[2] * gf; tb[1] = t[3] * gf; tb[2] = t[4] * gf; tb[3] = t[5] * gf; tb[4] = t[6]; tb[5] = t[7];
+    float pcx[4], pcy[4], tcx[4], tcy[4];
+    geom::corners(pb[0], pb[1], pb[2], pb[3], atan2f(pb[4], pb[5]), pcx, pcy);
+    geom::corners(tb[0], tb[1], tb[2], tb[3], atan2f(tb[4], tb[5]), tcx, tcy);
+    float* out = w.part + ((long)part * nT + k) * 12;
+    if (part == 0) {
+        const geom::InterPart ip = geom::inter_part<GIOU>(P, pcx, pcy, tcx, tcy);
+        out[0] = ip.inter;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { out[1 + i] = ip.dIx[i]; out[5 + i] = ip.dIy[i]; }
+    } else {
+        const geom::HullPart hp = geom::hull_part(P, pcx, pcy, tcx, tcy);
+        out[0] = hp.carea; out[1] = hp.sg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { out[2 + i] = hp.dy[i]; out[6 + i] = hp.dx[i]; }
+        out[10] = __int_as_float(hp.on);
+    }
+}
+
+template <bool GIOU>
+__global__ void __launch_bounds__(64) pairs_finish_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
+                                                          int G, int A, int C, Anchors an, Work w) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= nT) return;
     const int b = w.ti[k * 4];
     float* tf = w.tf + (long)k * 8;
@@ -121,7 +190,18 @@ __global__ void __launch_bounds__(64) pairs_kernel(const float* __restrict__ log
     const float* t = targets + (long)k * 8;
     const float gf = (float)G;
     tb[0] = t[2] * gf; tb[1] = t[3] * gf; tb[2] = t[4] * gf; tb[3] = t[5] * gf; tb[4] = t[6]; tb[5] = t[7];
-    const geom::PairOut o = geom::pair_term_t<GIOU>(pb, tb);
+    geom::InterPart ip;
+    geom::HullPart hp;
+    const float* pi = w.part + (long)k * 12;
+    const float* ph = w.part + ((long)nT + k) * 12;
+    ip.inter = pi[0];
+    hp.carea = GIOU ? ph[0] : 0.f; hp.sg = GIOU ? ph[1] : 0.f; hp.on = GIOU ? __float_as_int(ph[10]) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ip.dIx[i] = pi[1 + i]; ip.dIy[i] = pi[5 + i];
+        hp.dy[i] = GIOU ? ph[2 + i] : 0.f; hp.dx[i] = GIOU ? ph[6 + i] : 0.f;
+    }
+    const geom::PairOut o = geom::pair_finish<GIOU>(pb, tb, atan2f(pb[4], pb[5]), ip, hp);
     tf[0] = o.iou;
     tf[1] = o.term;
     for (int i = 0; i < 6; ++i) tf[2 + i] = o.g[i];
@@ -159,8 +239,11 @@ __global__ void __launch_bounds__(256) dense_kernel(const float* __restrict__ lo
         const float pc = sigmoidf_(t[6]);
         const float conf50 = pc > 0.5f ? 1.f : 0.f;
         acc[A_CONF50] += conf50;
+        // (g[] is only ever indexed by unrolled loop counters: a run-time index into a register array would bring the VGPR-index
+        // mode back, see geometry.hpp)
         float g[32];
-        for (int c = 0; c < NCH; ++c) g[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) g[c] = 0.f;
         if (!(fl & 1)) {
             acc[A_BCE_NOOBJ] += -fmaxf(log1pf(-pc), -100.f);
             acc[A_CONF_NOOBJ] += pc;
@@ -192,7 +275,9 @@ __global__ void __launch_bounds__(256) dense_kernel(const float* __restrict__ lo
             g[6] += sc.gobj / nObj * bce_grad(pc, 1.f) * pc * (1.f - pc);
             int arg = 0;
             float bestc = -1.f;
-            for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int c = 0; c < 25; ++c) {
+                if (c >= C) continue;
                 const float p = sigmoidf_(t[7 + c]);
                 const float tc = (fl >> (8 + c)) & 1 ? 1.f : 0.f;
                 acc[A_CLS] += -(tc * fmaxf(logf(p), -100.f) + (1.f - tc) * fmaxf(log1pf(-p), -100.f));
@@ -207,7 +292,9 @@ __global__ void __launch_bounds__(256) dense_kernel(const float* __restrict__ lo
             acc[A_DET50] += (iou > 0.5f ? 1.f : 0.f) * det;
             acc[A_DET75] += (iou > 0.75f ? 1.f : 0.f) * det;
         }
-        for (int c = 0; c < NCH; ++c) d[c] = g[c];
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            if (c < NCH) d[c] = g[c];
     }
     __shared__ double red[4][A_COUNT];
 #pragma unroll
@@ -223,36 +310,59 @@ __global__ void __launch_bounds__(256) dense_kernel(const float* __restrict__ lo
     }
 }
 
-__global__ void giou_grad_kernel(const float* __restrict__ logits, int nT, int G, int A, int C, Anchors an, float coef,
+// d(GIoU term)/d(logits).  Targets that share a (cell, anchor) add into the same six logits.  Instead of fp32 atomics (whose
+// order, and with it the last bits of d(logits), depended on what else ran on the GPU) the FIRST target of a cell sums the
+// contributions of all its targets in index order and is the only writer.  The search for a cell's targets is wave-wide: 64
+// candidates per __ballot instead of one dependent global load per candidate (28 us of latency per head with nT = 96).
+__global__ void __launch_bounds__(64) giou_grad_kernel(const float* __restrict__ logits, int nT, int G, int A, int C, Anchors an, float coef,
                                  Work w, float* dlogits) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nT) return;
-    const int b = w.ti[k * 4];
-    if (b < 0) return;
-    const int a = w.ti[k * 4 + 1], gj = w.ti[k * 4 + 2], gi = w.ti[k * 4 + 3];
-    // Targets that share a (cell, anchor) add into the same six logits.  Instead of fp32 atomics (whose order, and with it
-    // the last bits of d(logits), depended on what else ran on the GPU) the FIRST target of a cell sums the contributions of
-    // all its targets in index order and is the only writer: nT is ~100, the scan is free.
-    for (int j = 0; j < k; ++j)
-        if (w.ti[j * 4] == b && w.ti[j * 4 + 1] == a && w.ti[j * 4 + 2] == gj && w.ti[j * 4 + 3] == gi) return;
-    const int NCH = 7 + C;
-    const long base = ((long)(b * G + gj) * G + gi) * (A * NCH) + a * NCH;
-    const float* t = logits + base;
-    const float sx = sigmoidf_(t[0]), sy = sigmoidf_(t[1]);
-    const float e2 = expf(t[2]), e3 = expf(t[3]);
+    const int lane = threadIdx.x;
+    const int k = blockIdx.x * 64 + lane;
+    const bool live = k < nT;
+    // key of a target's (sample, anchor, row, column); rejected targets and idle lanes get keys that match nothing
+    auto key_of = [&](int j) -> long {
+        if (j >= nT) return -1L - j;
+        const int b = w.ti[j * 4];
+        if (b < 0) return -1L - j;
+        return (((long)b * MAXA + w.ti[j * 4 + 1]) * 4096 + w.ti[j * 4 + 2]) * 4096 + w.ti[j * 4 + 3];
+    };
+    const long mine = key_of(k);
+    const bool valid = live && mine >= 0;
+    bool first = valid;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j = k; j < nT; ++j) {
-        if (!(w.ti[j * 4] == b && w.ti[j * 4 + 1] == a && w.ti[j * 4 + 2] == gj && w.ti[j * 4 + 3] == gi)) continue;
-        const float* g = w.tf + (long)j * 8 + 2;
-        s[0] += coef * g[0] * sx * (1.f - sx);
-        s[1] += coef * g[1] * sy * (1.f - sy);
-        s[2] += e2 <= 1e3f ? coef * g[2] * e2 * an.w[a] : 0.f;
-        s[3] += e3 <= 1e3f ? coef * g[3] * e3 * an.h[a] : 0.f;
-        s[4] += coef * g[4];
-        s[5] += coef * g[5];
+    float sx = 0.f, sy = 0.f, e2 = 0.f, e3 = 0.f;
+    int a = 0;
+    long base = 0;
+    if (valid) {
+        const int b = w.ti[k * 4], gj = w.ti[k * 4 + 2], gi = w.ti[k * 4 + 3];
+        a = w.ti[k * 4 + 1];
+        const int NCH = 7 + C;
+        base = ((long)(b * G + gj) * G + gi) * (A * NCH) + a * NCH;
+        const float* t = logits + base;
+        sx = sigmoidf_(t[0]); sy = sigmoidf_(t[1]);
+        e2 = expf(t[2]); e3 = expf(t[3]);
     }
+    for (int j0 = 0; j0 < nT; j0 += 64) {
+        const long other = key_of(j0 + lane);          // lane l holds candidate j0 + l
+        for (int l = 0; l < 64 && j0 + l < nT; ++l) {
+            const long ko = __shfl(other, l);
+            const int j = j0 + l;
+            if (!valid || ko != mine) continue;
+            if (j < k) { first = false; continue; }     // an earlier target owns the cell's sum
+            if (!first) continue;
+            const float* g = w.tf + (long)j * 8 + 2;
+            s[0] += coef * g[0] * sx * (1.f - sx);
+            s[1] += coef * g[1] * sy * (1.f - sy);
+            s[2] += e2 <= 1e3f ? coef * g[2] * e2 * an.w[a] : 0.f;
+            s[3] += e3 <= 1e3f ? coef * g[3] * e3 * an.h[a] : 0.f;
+            s[4] += coef * g[4];
+            s[5] += coef * g[5];
+        }
+    }
+    if (valid && first) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dlogits[base + i] += s[i];
+        for (int i = 0; i < 6; ++i) dlogits[base + i] += s[i];
+    }
 }
 
 struct LossScales {
@@ -308,6 +418,7 @@ inline Work carve(void* ws, long cells, int nT, size_t* zero_bytes, size_t* tota
     if (zero_bytes) *zero_bytes = off;
     w.ti = (int*)(p + off); off += align_up(sizeof(int) * 4 * (size_t)(nT > 0 ? nT : 1), 256);
     w.tf = (float*)(p + off); off += align_up(sizeof(float) * 8 * (size_t)(nT > 0 ? nT : 1), 256);
+    w.part = (float*)(p + off); off += align_up(sizeof(float) * 24 * (size_t)(nT > 0 ? nT : 1), 256);
     if (total_bytes) *total_bytes = off;
     return w;
 }
@@ -348,7 +459,7 @@ extern "C" int cy_yolo_decode(const float* logits, int B, int G, int A, int C, c
 extern "C" int cy_head_scratch_bytes(void) {
     CY_ENTER();
     const void* fns[] = {(const void*)assign_kernel, (const void*)pairs_kernel<true>, (const void*)pairs_kernel<false>,
-                         (const void*)giou_grad_kernel};
+                         (const void*)pairs_finish_kernel<true>, (const void*)pairs_finish_kernel<false>, (const void*)giou_grad_kernel};
     int worst = 0;
     for (const void* f : fns) {
         hipFuncAttributes a;
@@ -391,9 +502,15 @@ extern "C" int cy_yolo_loss(const float* logits, int B, int G, int A, int C, con
     }
     const int tb = (nT + 63) / 64;
     if (nT > 0) {
-        hipLaunchKernelGGL(assign_kernel, dim3(tb), dim3(64), 0, cy_s(s), targets, nT, B, G, A, an, ignore_thresh, w);
-        if (use_giou) hipLaunchKernelGGL(pairs_kernel<true>, dim3(tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, w);
-        else hipLaunchKernelGGL(pairs_kernel<false>, dim3(tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, w);
+        const int ta = (nT + 64 / LPT - 1) / (64 / LPT);      // 4 lanes per target
+        hipLaunchKernelGGL(assign_kernel, dim3(ta), dim3(64), 0, cy_s(s), targets, nT, B, G, A, an, ignore_thresh, w);
+        if (use_giou) {      // clip blocks + hull blocks in one grid, then the join
+            hipLaunchKernelGGL(pairs_kernel<true>, dim3(2 * tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, w, tb);
+            hipLaunchKernelGGL(pairs_finish_kernel<true>, dim3(tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, w);
+        } else {
+            hipLaunchKernelGGL(pairs_kernel<false>, dim3(tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, w, tb);
+            hipLaunchKernelGGL(pairs_finish_kernel<false>, dim3(tb), dim3(64), 0, cy_s(s), logits, targets, nT, G, A, C, an, w);
+        }
     }
     const int grid = (int)((cells + 255) / 256 > 2048 ? 2048 : (cells + 255) / 256);
     hipLaunchKernelGGL(dense_kernel, dim3(grid), dim3(256), 0, cy_s(s), logits, targets, B, G, A, C, an, sc, w, dlogits);

@@ -328,14 +328,16 @@ class Engine:
 
     def _f_yolo(self, rec, targets, use_giou, img_size):
         if (self.side is not None and targets is not None and not self._in_side_head
-                and os.environ.get('CY_HEADS_SIDE', '1') != '0' and self._heads_side_ok()):
-            # training: the decode + loss kernels of a head are a dozen two-wave launches (one lane per target in the
-            # polygon clip), ~0.15 ms of latency that nothing downstream needs before the loss is read -- they run on the
-            # side stream beside the trunk convs that follow the head (forward() joins the streams at the end): +1 %.
-            # This needs the per-target kernels to be free of scratch memory (csrc/yolo_head.hip, build.py): with their
-            # polygon arrays in scratch they returned different owners / IoUs in ~1 % of launches whenever another kernel
-            # ran beside them (tools/head_race_probe.py); and the GIoU gradient of targets sharing a cell has one writer
-            # summing in index order instead of fp32 atomics.  cy_yolo_loss is bit-reproducible whatever runs beside it.
+                and os.environ.get('CY_HEADS_SIDE', '0') == '1' and self._heads_side_ok()):
+            # OPT-IN (CY_HEADS_SIDE=1; default off since round 3).  The decode + loss kernels of a head are a dozen one-wave
+            # launches, ~0.1 ms of latency that nothing downstream needs before the loss is read; on the side stream they hide
+            # beside the trunk convs that follow the head (+1 %).  But the GIoU kernels are NOT reproducible beside two of our
+            # conv instantiations: tools/head_race_probe2.py shows 0.2-2.5 % of launches with a wrong clip / hull in lanes 48-63 of
+            # a wave whenever igemm_fast<192,128> or the pipelined 384 x 128 tile runs on another stream -- never beside torch
+            # GEMMs, elementwise kernels, BN passes, weight-gradient kernels or the lower-register conv tiles, never alone, and
+            # no other kernel of the step is disturbed (tools/victim_probe.py).  Scratch memory (round 2's suspect), the
+            # VGPR-index mode and uninitialised registers / LDS are ruled out (profiles/r03_head_race.txt); the mechanism is
+            # not found.  Until it is, the heads run where nothing runs beside them.
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side.wait_event(ev)

@@ -35,6 +35,10 @@ enum { CY_CONV_TILE_SHIFT = 8 };
 #define CY_CONV_TILE(h) ((h) << CY_CONV_TILE_SHIFT)
 
 int cy_version(void);
+/* Test instrument: a kernel of `blocks` x 256 threads that writes `pattern` into (almost) every VGPR of its waves and into
+ * `lds_bytes` of LDS and exits -- run beside another kernel it exposes that kernel's reads of uninitialised registers / LDS
+ * (tools/head_race_probe2.py).  No reference counterpart. */
+int cy_probe_dirty(uint32_t pattern, int blocks, int lds_bytes, uint32_t* sink, cy_stream_t s);
 /* Number of compute units / wavefront size of the current device (sanity for the loader). */
 int cy_device_info(int* cus, int* wave);
 
