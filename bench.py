@@ -283,6 +283,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the brief measurement of the other configurations')
+    ap.add_argument('--graph', type=int, default=0, help='1: the step as one captured hipGraph (graphed.GraphedTrainStep); default 0 = '
+                    'eager launches: on ROCm 7.2 the replay of the 660-node, two-stream graph takes 33.1 ms against 19.2 ms eager '
+                    '(DESIGN.md section 5), so the measured configuration is the eager one')
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     a.batch = a.batch or cfg['batch']
@@ -329,14 +332,33 @@ def main():
     net = RcclDataParallel(model) if (world > 1 or force_ddp) else model
     opt = create_optimizer(_OptCfg, model)          # FusedAdam (cy_adam_multi) on the device
     source = batch_source(dev, a.batch, a.size, bool(cfg.get('mosaic')), seed=rank)
+    use_graph = bool(a.graph) and world == 1 and not force_ddp and hasattr(opt, 'capturable')
+    graphed, graph_note = None, 'eager launches'
+    if use_graph:
+        from complex_yolov4_pytorch_amd.graphed import GraphedTrainStep
+        opt.capturable = True
+        graphed = GraphedTrainStep(model, opt)
 
-    def step():
+    def eager_step():
         opt.zero_grad(set_to_none=True)
         x, tg = source()
         loss, _ = net(x, tg)
         loss.backward()
         opt.step()
         return loss
+
+    def step():
+        if graphed is not None:
+            return graphed(*source())       # the whole step = one hipGraphLaunch (captured at the first call of a shape)
+        return eager_step()
+
+    if graphed is not None:
+        try:
+            step()
+            graph_note = 'one captured hipGraph per step (graphed.GraphedTrainStep)'
+        except Exception as e:      # noqa: BLE001 -- a capture failure must not cost the measurement
+            graphed, graph_note = None, 'eager launches (graph capture failed: %r)' % (e,)
+            opt.capturable = False
 
     def sync():
         if world > 1:
@@ -368,7 +390,7 @@ def main():
         if rank == 0:
             ops.PROFILER = ops.LaunchProfiler()
         for _ in range(2):
-            step()
+            eager_step()        # (the launch brackets are host-side event records: the probe steps run eagerly)
         summ = ops.PROFILER.summary() if rank == 0 else {}
         if rank == 0:
             # the same launches split by which roof bounds them: arithmetic intensity above / below the ridge point.
@@ -469,7 +491,7 @@ def main():
             'config': {'workload': 'complex_yolov4.cfg train step (%sfwd + rotated-GIoU loss + bwd + Adam), batch %d per GPU, %dx%dx3 synthetic BEV, %d targets/image'
                                    % ('device mosaic of four maps per sample + ' if cfg.get('mosaic') else '', a.batch, a.size, a.size, 24 if cfg.get('mosaic') else 6),
                        'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4),
-                       'deterministic': bool(a.deterministic),
+                       'deterministic': bool(a.deterministic), 'issue': graph_note,
                        'dgrad_bn_sums_layers': fused_layers},
             'roofline': roofline, 'cpu_baseline': cpu,
         }

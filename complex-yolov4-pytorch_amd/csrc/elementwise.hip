@@ -730,20 +730,24 @@ struct AdamGroups {
 __global__ void __launch_bounds__(256) adam_multi_kernel(const cy_adam_desc* __restrict__ desc, const int* __restrict__ blocks,
                                                         float beta1, float beta2, float eps, float bc1, float bc2,
                                                         int zero_grad, AdamGroups grp, const int* __restrict__ skip,
-                                                        const int* __restrict__ step_in, int* __restrict__ step_out) {
+                                                        const int* __restrict__ step_in, int* __restrict__ step_out,
+                                                        const float* __restrict__ grp_dev) {
     const bool skipped = skip && *skip;   // a non-finite gradient was found (cy_grad_nonfinite): the step is skipped as a whole
     if (step_in) {
         // step count on the device (cy_adam_multi_dev): a skipped step does not advance it, so the bias corrections of
-        // the next step are those of t, not t + 1 -- without the host ever reading the flag
-        const int t = *step_in + 1;
-        if (blockIdx.x == 0 && threadIdx.x == 0) *step_out = skipped ? t - 1 : t;
+        // the next step are those of t, not t + 1 -- without the host ever reading the flag.  step_out == nullptr: the
+        // counter was already advanced for this step by cy_step_tick (the replayable form: same pointers every step).
+        const int t = step_out ? *step_in + 1 : *step_in;
+        if (step_out && blockIdx.x == 0 && threadIdx.x == 0) *step_out = skipped ? t - 1 : t;
         bc1 = (float)(1.0 - pow((double)beta1, (double)t));
         bc2 = (float)(1.0 - pow((double)beta2, (double)t));
     }
     if (skipped) return;
     const cy_adam_desc d = desc[blocks[2 * blockIdx.x]];
     const long first = (long)blocks[2 * blockIdx.x + 1] * 256;
-    const float lr = grp.lr[d.group & 7], wdecay = grp.wd[d.group & 7];
+    // learning rate / weight decay per group: by value, or from a device array [lr x 8, wd x 8] (a captured launch reads it anew)
+    const float lr = grp_dev ? grp_dev[d.group & 7] : grp.lr[d.group & 7];
+    const float wdecay = grp_dev ? grp_dev[8 + (d.group & 7)] : grp.wd[d.group & 7];
     const float step = lr / bc1, rs2 = rsqrtf(bc2);
 #pragma unroll
     for (int it = 0; it < CY_MULTI_ELEMS / 256; ++it) {
@@ -1281,7 +1285,7 @@ extern "C" int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, in
         grp.wd[i] = i < ngroups ? group_wd_host[i] : 0.f;
     }
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, beta1, beta2, eps, bias_corr1,
-                       bias_corr2, zero_grad, grp, (const int*)skip_flag, (const int*)nullptr, (int*)nullptr);
+                       bias_corr2, zero_grad, grp, (const int*)skip_flag, (const int*)nullptr, (int*)nullptr, (const float*)nullptr);
     CY_LAUNCH_CHECK();
     return 0;
 }
@@ -1299,7 +1303,26 @@ extern "C" int cy_adam_multi_dev(const cy_adam_desc* desc, const int32_t* blocks
         grp.wd[i] = i < ngroups ? group_wd_host[i] : 0.f;
     }
     hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, beta1, beta2, eps, 1.f, 1.f,
-                       zero_grad, grp, (const int*)skip_flag, (const int*)step_in, (int*)step_out);
+                       zero_grad, grp, (const int*)skip_flag, (const int*)step_in, (int*)step_out, (const float*)nullptr);
+    CY_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void step_tick_kernel(int* __restrict__ counter, const int* __restrict__ skip) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !(skip && *skip)) *counter += 1;
+}
+
+// The replayable (hipGraph-capturable) optimizer step: nothing that changes from step to step is passed by value.
+extern "C" int cy_adam_multi_graph(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2,
+                                   float eps, int32_t* step_counter, const float* group_lr_wd_dev, int zero_grad,
+                                   const int32_t* skip_flag, cy_stream_t s) {
+    CY_ENTER();
+    if (!desc || !blocks || nblocks < 1 || !step_counter || !group_lr_wd_dev) return CY_ERR_ARG;
+    AdamGroups grp;
+    for (int i = 0; i < 8; ++i) { grp.lr[i] = 0.f; grp.wd[i] = 0.f; }
+    hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, cy_s(s), (int*)step_counter, (const int*)skip_flag);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, beta1, beta2, eps, 1.f, 1.f,
+                       zero_grad, grp, (const int*)skip_flag, (const int*)step_counter, (int*)nullptr, group_lr_wd_dev);
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -161,6 +161,11 @@ class Engine:
     def forward(self, x, targets, params, use_giou, img_size, weights_epoch=None):
         plan = self.plan
         self.fwd_serial += 1
+        if self.stats_pair is not None and self.training:
+            # the alternating statistics tables restart from a defined state every pass (complex_yolov4.cfg has an ODD number of
+            # BatchNorm layers: the parity used to carry over from step to step, which a captured and replayed step cannot do)
+            self._sp = 0
+            self.stats_pair[0].zero_()
         with self._scope():
             ops.nchw_to_nhwc(x, plan.input.C, self.dt, out=self.view(plan.input))
             self.params = params
@@ -381,6 +386,10 @@ class Engine:
         if self._reduce_groups is None or self._reduce_key != grads[next(iter(grads))].data_ptr():
             self._build_reduce_groups()
         flush_at = {g['last']: g for g in self._reduce_groups}
+        if self.bnpart_pair is not None:
+            self._bp = 0
+            self.bnpart_pair[0].zero_()
+            self.bnpart_pair[1].zero_()
         with self._scope():
             for rec in self.plan.bwd:
                 getattr(self, '_b_' + rec['op'])(rec)

@@ -303,6 +303,12 @@ def adam_multi_dev(desc, blocks, beta1, beta2, eps, step_in, step_out, lrs, wds,
                _p(step_out), int(zero_grad), _farr(lrs), _farr(wds), len(lrs), _p(skip_flag), _stream())
 
 
+def adam_multi_graph(desc, blocks, beta1, beta2, eps, step_counter, group_lr_wd, zero_grad=False, skip_flag=None):
+    """cy_adam_multi_graph: step counter and (lr x 8, wd x 8) on the device -- the capturable form."""
+    lib().call('cy_adam_multi_graph', _p(desc), _p(blocks), blocks.shape[0], float(beta1), float(beta2), float(eps),
+               _p(step_counter), _p(group_lr_wd), int(zero_grad), _p(skip_flag), _stream())
+
+
 def nchw_to_nhwc(x, cpad, dt, out=None):
     _require_gpu()
     N, C, H, W = x.shape

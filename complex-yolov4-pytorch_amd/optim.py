@@ -11,8 +11,15 @@ from . import ops
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """``capturable=True`` (the name torch.optim.Adam uses for the same purpose): nothing that changes from step to step is
+    passed to the kernel by value -- the step count lives in a device int32 advanced by the launch itself, the per-group
+    learning rates / weight decays in a device array refreshed from a pinned host copy -- so ``step()`` can be captured in a
+    hipGraph (graphed.GraphedTrainStep) and replayed while LR schedulers keep editing ``param_groups``."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = bool(capturable)
+        self._counter = self._grp_dev = self._grp_host = None
         self._table = self._key = None
         self._steps = 0
         self._step_dev = None          # int32 [2] ping-pong step counter, used while a device skip flag is attached
@@ -34,6 +41,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._steps = max(steps) if steps else 0
         self._table = self._key = None
         self._step_dev = None
+        self._counter = None
 
     def note_skipped(self):
         """A step the device skip flag suppressed (DynamicLossScale found a non-finite gradient) did not happen.  The
@@ -43,6 +51,16 @@ class FusedAdam(torch.optim.Optimizer):
         self._steps = max(0, self._steps - 1)
         for st in self.state.values():
             st['step'] = self._steps
+
+    def refresh_groups(self):
+        """param_groups' (lr, weight_decay) -> the pinned host array the captured copy reads (capturable mode)."""
+        for i, g in enumerate(self.param_groups):
+            self._grp_host[i] = float(g['lr'])
+            self._grp_host[8 + i] = float(g['weight_decay'])
+
+    def note_replayed(self):
+        """A captured step() was replayed by a graph (graphed.GraphedTrainStep): keep the host's step bookkeeping in line."""
+        self._steps += 1
 
     def _build(self):
         items = []
@@ -76,6 +94,17 @@ class FusedAdam(torch.optim.Optimizer):
         assert len(self.param_groups) <= 8
         skip = getattr(self, 'skip_flag', None)
         lrs, wds = [g['lr'] for g in self.param_groups], [g['weight_decay'] for g in self.param_groups]
+        if self.capturable:
+            dev = self._table[0].device
+            if self._counter is None:
+                self._counter = torch.full((1,), self._steps - 1, dtype=torch.int32, device=dev)
+                self._grp_dev = torch.zeros(16, dtype=torch.float32, device=dev)
+                self._grp_host = torch.zeros(16, dtype=torch.float32).pin_memory()
+            self.refresh_groups()
+            self._grp_dev.copy_(self._grp_host, non_blocking=True)     # (captured: re-read from the pinned copy at every replay)
+            ops.adam_multi_graph(self._table[0], self._table[1], b1, b2, self.param_groups[0]['eps'], self._counter, self._grp_dev,
+                                 zero_grad=zero_grad, skip_flag=skip)
+            return loss
         if skip is not None:
             if self._step_dev is None:       # first step under a skip flag (or after a resume): seed the device counter
                 self._step_dev = torch.full((2,), self._steps - 1, dtype=torch.int32, device=skip.device)

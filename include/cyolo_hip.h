@@ -95,6 +95,13 @@ int cy_adam_multi(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, 
 int cy_adam_multi_dev(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2, float eps,
                       const int32_t* step_in, int32_t* step_out, int zero_grad, const float* group_lr_host,
                       const float* group_wd_host, int ngroups, const int32_t* skip_flag, cy_stream_t s);
+/* The hipGraph-capturable form of the step: the step count is a device int32 advanced by a one-thread kernel in the same
+ * call (not when *skip_flag is set), bias corrections are computed from it in the kernel, and the per-group learning rates /
+ * weight decays are read from a device array [lr x 8, wd x 8] -- so a captured launch needs no re-capture when the step
+ * number or the learning-rate schedule moves on.  Same arithmetic as cy_adam_multi. */
+int cy_adam_multi_graph(const cy_adam_desc* desc, const int32_t* blocks, int nblocks, float beta1, float beta2, float eps,
+                        int32_t* step_counter, const float* group_lr_wd_dev, int zero_grad, const int32_t* skip_flag,
+                        cy_stream_t s);
 /* Fused multi-tensor SGD with momentum / Nesterov (torch.optim.SGD semantics, dampening 0): the reference's other
  * optimizer choice (src/utils/train_utils.py:35-37: SGD(lr, momentum, nesterov=True)).  Uses cy_adam_desc with `m` as the
  * momentum buffer (`v` unused, may be NULL); first_step != 0 initialises the buffer with the gradient as torch does. */

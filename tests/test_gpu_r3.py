@@ -272,3 +272,42 @@ def test_direct1x1_dgrad_bn_sums_and_prefetched_fan_in(dt, accum, case):
         g3 = View.alloc(N, H, H, Cg, code); g3.buf.copy_(base)
         ops.conv_igemm(dy, wd, Cg, g3, 1, 1, 0, flags=flags, tile=10)                # the same kernel without the sums
         assert torch.equal(g3.buf, g2.buf)
+
+
+def test_graphed_train_step_equals_eager_steps():
+    """graphed.GraphedTrainStep (forward + loss + backward + Adam as ONE captured hipGraph, replayed) against the same steps
+    issued eagerly, deterministic mode: parameters, BatchNorm running statistics and losses after three different batches are
+    bit-identical; a learning-rate change between replays is honoured without re-capture; a new target count captures a
+    second graph."""
+    import copy
+    from complex_yolov4_pytorch_amd.graphed import GraphedTrainStep
+    from complex_yolov4_pytorch_amd.optim import FusedAdam
+    batches = [(syn.bev_images(2, 416, seed=40 + i).to(DEV), syn.targets(2, 6, 416, seed=40 + i).to(DEV)) for i in range(3)]
+    extra = (syn.bev_images(2, 416, seed=50).to(DEV), syn.targets(2, 5, 416, seed=50).to(DEV))       # 10 target rows instead of 12
+    runs = []
+    for graphed in (False, True):
+        model = _model('complex_yolov4.cfg', 'f16', deterministic=True)
+        model.train()
+        opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, capturable=True)
+
+        def eager(x, tg, model=model, opt=opt):
+            opt.zero_grad(set_to_none=True)
+            loss, _ = model(x, tg)
+            loss.backward()
+            opt.step()
+            return loss
+        eager(*batches[0])                                        # both arms: one eager step first (tuning, state, workspaces)
+        step = GraphedTrainStep(model, opt, warmup=0) if graphed else eager
+        losses = []
+        for i, (x, tg) in enumerate(batches + [extra]):
+            if i == 2:
+                for g in opt.param_groups:
+                    g['lr'] = 3e-4                                 # an LR schedule moving on between steps
+            losses.append(float(step(x, tg).detach()))
+        torch.cuda.synchronize()
+        if graphed:
+            assert step.replays == 4 and len(step._graphs) == 2
+        runs.append((losses, copy.deepcopy({k: v.detach().clone() for k, v in model.state_dict().items()})))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    for k, v in runs[0][1].items():
+        assert torch.equal(v, runs[1][1][k]), k
