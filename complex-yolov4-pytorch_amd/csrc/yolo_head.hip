@@ -30,10 +30,24 @@ struct Work {
     float* part;    // [2][nT][12]  the two halves of a pair term: intersection (inter, dIx[4], dIy[4]) / hull (carea, sg, dy[4], dx[4], on)
 };
 
+// Everything that differs between the heads of one model, for the three-heads-in-one-launch forms (cy_yolo_loss_multi): passed by
+// value, head = blockIdx.y (a switch over three kernel arguments, so a lane-varying anchor index stays a load from the kernel
+// argument segment exactly as in the single-head kernels).
+struct HeadP {
+    const float* logits;
+    float* dlogits;
+    float* metrics;
+    int G, row_offset;
+    float stride;
+    long cells;
+    Anchors an_dec, an;      // decode anchors (w, h in grid units), loss anchors (w, h in grid units, im, re)
+    Work w;
+};
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ void decode_kernel(const float* __restrict__ logits, int B, int G, int A, int C, Anchors an, float stride,
-                              float* __restrict__ out, int rows_total, int row_offset) {
+__device__ __forceinline__ void decode_body(const float* __restrict__ logits, int B, int G, int A, int C, const Anchors& an, float stride,
+                                            float* __restrict__ out, int rows_total, int row_offset) {
     const int NCH = 7 + C;
     const long total = (long)B * G * G * A;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -51,6 +65,17 @@ __global__ void decode_kernel(const float* __restrict__ logits, int B, int G, in
         for (int c = 6; c < NCH; ++c) o[c] = sigmoidf_(t[c]);
     }
 }
+__global__ void decode_kernel(const float* __restrict__ logits, int B, int G, int A, int C, Anchors an, float stride,
+                              float* __restrict__ out, int rows_total, int row_offset) {
+    decode_body(logits, B, G, A, C, an, stride, out, rows_total, row_offset);
+}
+#define CY_HEAD_SWITCH(call)                                                       \
+    if (blockIdx.y == 0) { const HeadP& h = h0; call; }                           \
+    else if (blockIdx.y == 1) { const HeadP& h = h1; call; }                      \
+    else { const HeadP& h = h2; call; }
+__global__ void decode3_kernel(HeadP h0, HeadP h1, HeadP h2, int B, int A, int C, float* __restrict__ out, int rows_total) {
+    CY_HEAD_SWITCH(decode_body(h.logits, B, h.G, A, C, h.an_dec, h.stride, out, rows_total, h.row_offset))
+}
 
 // Wave-cooperative target assignment (reference yolo_layer.py:69-142 with iou_rotated_boxes_utils.py:64-96 per anchor): LPT = 4
 // lanes per target, lane `sub` clips the target against anchors sub, sub + 4, ... (the float64 convex clip, the long pole of
@@ -61,9 +86,8 @@ __global__ void decode_kernel(const float* __restrict__ logits, int B, int G, in
 // per-target kernels are promoted to registers.  They were the only kernels of the step with scratch memory -- 368 and 880
 // bytes per lane -- and the ones whose results changed when another kernel ran beside them: tools/head_race_probe.py)
 constexpr int LPT = 4;
-__global__ void __launch_bounds__(64) assign_kernel(const float* __restrict__ targets, int nT, int B, int G, int A, Anchors an,
-                              float ignore_thresh, Work w) {
-    CY_GEOM_POOL(P);
+__device__ __forceinline__ void assign_body(const geom::Pool& P, const float* __restrict__ targets, int nT, int B, int G, int A,
+                                            const Anchors& an, float ignore_thresh, const Work& w) {
     const int lane = threadIdx.x, sub = lane & (LPT - 1);
     const int k = blockIdx.x * (64 / LPT) + (lane >> 2);
     const bool live = k < nT;
@@ -122,6 +146,17 @@ __global__ void __launch_bounds__(64) assign_kernel(const float* __restrict__ ta
     }
 }
 
+__global__ void __launch_bounds__(64) assign_kernel(const float* __restrict__ targets, int nT, int B, int G, int A, Anchors an,
+                                                    float ignore_thresh, Work w) {
+    CY_GEOM_POOL(P);
+    assign_body(P, targets, nT, B, G, A, an, ignore_thresh, w);
+}
+__global__ void __launch_bounds__(64) assign3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int nT, int B, int A,
+                                                     float ignore_thresh) {
+    CY_GEOM_POOL(P);
+    CY_HEAD_SWITCH(assign_body(P, targets, nT, B, h.G, A, h.an, ignore_thresh, h.w))
+}
+
 __device__ __forceinline__ void decode_box(const float* t, int gi, int gj, float aw, float ah, float* box) {
     box[0] = sigmoidf_(t[0]) + (float)gi;
     box[1] = sigmoidf_(t[1]) + (float)gj;
@@ -137,9 +172,8 @@ __device__ __forceinline__ void decode_box(const float* t, int gi, int gj, float
 // one lane per target each, every wave executing a single code path (two lanes of a wave would run the halves one after the
 // other: divergence serialises them) -- and leave their results in the workspace; pairs_finish_kernel joins them.
 template <bool GIOU>
-__global__ void __launch_bounds__(64) pairs_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
-                                                   int G, int A, int C, Anchors an, Work w, int nb) {
-    CY_GEOM_POOL(P);
+__device__ __forceinline__ void pairs_body(const geom::Pool& P, const float* __restrict__ logits, const float* __restrict__ targets, int nT,
+                                           int G, int A, int C, const Anchors& an, const Work& w, int nb) {
     const int part = (int)blockIdx.x >= nb ? 1 : 0;
     const int k = ((int)blockIdx.x - part * nb) * 64 + (int)threadIdx.x;
     if (k >= nT) return;
@@ -172,8 +206,20 @@ __global__ void __launch_bounds__(64) pairs_kernel(const float* __restrict__ log
 }
 
 template <bool GIOU>
-__global__ void __launch_bounds__(64) pairs_finish_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
-                                                          int G, int A, int C, Anchors an, Work w) {
+__global__ void __launch_bounds__(64) pairs_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
+                                                   int G, int A, int C, Anchors an, Work w, int nb) {
+    CY_GEOM_POOL(P);
+    pairs_body<GIOU>(P, logits, targets, nT, G, A, C, an, w, nb);
+}
+template <bool GIOU>
+__global__ void __launch_bounds__(64) pairs3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int nT, int A, int C, int nb) {
+    CY_GEOM_POOL(P);
+    CY_HEAD_SWITCH(pairs_body<GIOU>(P, h.logits, targets, nT, h.G, A, C, h.an, h.w, nb))
+}
+
+template <bool GIOU>
+__device__ __forceinline__ void pairs_finish_body(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
+                                                  int G, int A, int C, const Anchors& an, const Work& w) {
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= nT) return;
     const int b = w.ti[k * 4];
@@ -208,6 +254,16 @@ __global__ void __launch_bounds__(64) pairs_finish_kernel(const float* __restric
     atomicAdd(&w.acc[A_GIOU], (double)o.term);
 }
 
+template <bool GIOU>
+__global__ void __launch_bounds__(64) pairs_finish_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
+                                                          int G, int A, int C, Anchors an, Work w) {
+    pairs_finish_body<GIOU>(logits, targets, nT, G, A, C, an, w);
+}
+template <bool GIOU>
+__global__ void __launch_bounds__(64) pairs_finish3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int nT, int A, int C) {
+    CY_HEAD_SWITCH(pairs_finish_body<GIOU>(h.logits, targets, nT, h.G, A, C, h.an, h.w))
+}
+
 __device__ __forceinline__ float bce_grad(float p, float t) {
     // d BCE / d p as torch computes it: (p - t) / max((1-p)*p, 1e-12)
     return (p - t) / fmaxf((1.f - p) * p, 1e-12f);
@@ -217,9 +273,9 @@ struct Scales {
     float gx, gy, gw, gh, geul, gobj, gnoobj, gcls;  // d total / d (mean terms)
 };
 
-__global__ void __launch_bounds__(256) dense_kernel(const float* __restrict__ logits, const float* __restrict__ targets,
-                                                    int B, int G, int A, int C, Anchors an, Scales sc, Work w,
-                                                    float* __restrict__ dlogits) {
+__device__ __forceinline__ void dense_body(const float* __restrict__ logits, const float* __restrict__ targets,
+                                           int B, int G, int A, int C, const Anchors& an, const Scales& sc, const Work& w,
+                                           float* __restrict__ dlogits) {
     const int NCH = 7 + C;
     const long cells = (long)B * A * G * G;
     const float nObj = (float)w.cnt[C_NOBJ];
@@ -309,13 +365,22 @@ __global__ void __launch_bounds__(256) dense_kernel(const float* __restrict__ lo
         if (v != 0.0) atomicAdd(&w.acc[threadIdx.x], v);
     }
 }
+__global__ void __launch_bounds__(256) dense_kernel(const float* __restrict__ logits, const float* __restrict__ targets,
+                                                    int B, int G, int A, int C, Anchors an, Scales sc, Work w,
+                                                    float* __restrict__ dlogits) {
+    dense_body(logits, targets, B, G, A, C, an, sc, w, dlogits);
+}
+__global__ void __launch_bounds__(256) dense3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int B, int A, int C,
+                                                     Scales sc) {
+    CY_HEAD_SWITCH(dense_body(h.logits, targets, B, h.G, A, C, h.an, sc, h.w, h.dlogits))
+}
 
 // d(GIoU term)/d(logits).  Targets that share a (cell, anchor) add into the same six logits.  Instead of fp32 atomics (whose
 // order, and with it the last bits of d(logits), depended on what else ran on the GPU) the FIRST target of a cell sums the
 // contributions of all its targets in index order and is the only writer.  The search for a cell's targets is wave-wide: 64
 // candidates per __ballot instead of one dependent global load per candidate (28 us of latency per head with nT = 96).
-__global__ void __launch_bounds__(64) giou_grad_kernel(const float* __restrict__ logits, int nT, int G, int A, int C, Anchors an, float coef,
-                                 Work w, float* dlogits) {
+__device__ __forceinline__ void giou_grad_body(const float* __restrict__ logits, int nT, int G, int A, int C, const Anchors& an, float coef,
+                                               const Work& w, float* dlogits) {
     const int lane = threadIdx.x;
     const int k = blockIdx.x * 64 + lane;
     const bool live = k < nT;
@@ -364,12 +429,19 @@ __global__ void __launch_bounds__(64) giou_grad_kernel(const float* __restrict__
         for (int i = 0; i < 6; ++i) dlogits[base + i] += s[i];
     }
 }
+__global__ void __launch_bounds__(64) giou_grad_kernel(const float* __restrict__ logits, int nT, int G, int A, int C, Anchors an, float coef,
+                                                       Work w, float* dlogits) {
+    giou_grad_body(logits, nT, G, A, C, an, coef, w, dlogits);
+}
+__global__ void __launch_bounds__(64) giou_grad3_kernel(HeadP h0, HeadP h1, HeadP h2, int nT, int A, int C, float coef) {
+    CY_HEAD_SWITCH(giou_grad_body(h.logits, nT, h.G, A, C, h.an, coef, h.w, h.dlogits))
+}
 
 struct LossScales {
     float noobj, obj, lgiou, leular, lobj, lcls;
 };
 
-__global__ void finalize_kernel(Work w, long cells, int nT, int C, int use_giou, LossScales ls, float* metrics) {
+__device__ __forceinline__ void finalize_body(const Work& w, long cells, int nT, int C, int use_giou, const LossScales& ls, float* metrics) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double nObj = (double)w.cnt[C_NOBJ];
     const double nNo = (double)(cells - w.cnt[C_NCLEARED]);
@@ -403,6 +475,12 @@ __global__ void finalize_kernel(Work w, long cells, int nT, int C, int use_giou,
     metrics[17] = (float)(a[A_CONF_NOOBJ] / nNo);
     metrics[18] = (float)nObj;
     metrics[19] = (float)w.cnt[C_ERR];
+}
+__global__ void finalize_kernel(Work w, long cells, int nT, int C, int use_giou, LossScales ls, float* metrics) {
+    finalize_body(w, cells, nT, C, use_giou, ls, metrics);
+}
+__global__ void finalize3_kernel(HeadP h0, HeadP h1, HeadP h2, int nT, int C, int use_giou, LossScales ls) {
+    CY_HEAD_SWITCH(finalize_body(h.w, h.cells, nT, C, use_giou, ls, h.metrics))
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -475,6 +553,107 @@ extern "C" int64_t cy_yolo_loss_workspace(int B, int G, int A, int C, int nT) {
     size_t z, total;
     (void)carve(nullptr, cells, nT, &z, &total);
     return (int64_t)total;
+}
+
+// One workspace for all the heads of a model: the regions cy_yolo_loss_multi zeroes (accumulators, counters, ownership maps of
+// every head) come first and contiguous -- ONE memset -- then every head's target tables.
+static size_t carve_multi(void* ws, int nheads, const int* Gs, int B, int A, int nT, Work* out, size_t* zero_bytes) {
+    unsigned char* p = (unsigned char*)ws;
+    size_t off = 0;
+    for (int h = 0; h < nheads; ++h) {
+        const long cells = (long)B * A * Gs[h] * Gs[h];
+        Work& w = out[h];
+        w.acc = (double*)(p + off); off += align_up(sizeof(double) * A_COUNT, 256);
+        w.cnt = (int*)(p + off); off += 256;
+        w.owner = (int*)(p + off); off += align_up(sizeof(int) * cells, 256);
+        w.flags = (int*)(p + off); off += align_up(sizeof(int) * cells, 256);
+    }
+    if (zero_bytes) *zero_bytes = off;
+    const size_t n1 = (size_t)(nT > 0 ? nT : 1);
+    for (int h = 0; h < nheads; ++h) {
+        Work& w = out[h];
+        w.ti = (int*)(p + off); off += align_up(sizeof(int) * 4 * n1, 256);
+        w.tf = (float*)(p + off); off += align_up(sizeof(float) * 8 * n1, 256);
+        w.part = (float*)(p + off); off += align_up(sizeof(float) * 24 * n1, 256);
+    }
+    return off;
+}
+
+extern "C" int64_t cy_yolo_loss_multi_workspace(int nheads, const int* Gs_host, int B, int A, int C, int nT) {
+    (void)C;
+    if (nheads < 1 || nheads > 3 || !Gs_host) return -1;
+    Work w[3];
+    return (int64_t)carve_multi(nullptr, nheads, Gs_host, B, A, nT, w, nullptr);
+}
+
+// Decode + loss of up to three heads in ONE sequence of launches (head = blockIdx.y): 9 launches per step instead of 8 per head.
+// The heads are a chain of one-wave kernels that is pure latency (~0.1 ms per head); since round 3 they run on the trunk's stream
+// (profiles/r03_head_race.txt), where that latency is on the critical path.  Same kernels bodies, same arithmetic and the same
+// results as cy_yolo_decode + cy_yolo_loss per head.
+extern "C" int cy_yolo_loss_multi(int nheads, const cy_head_in* heads_host, int B, int A, int C, const float* targets, int nT,
+                                  float img_size, float ignore_thresh, int use_giou, void* workspace, float* out, int rows_total,
+                                  cy_stream_t s) {
+    CY_ENTER();
+    if (nheads < 1 || nheads > 3 || !heads_host || !workspace || nT < 0 || (nT > 0 && !targets)) return CY_ERR_ARG;
+    if (C < 1 || C > 23 || 7 + C > 32 || A < 1 || A > MAXA) return CY_ERR_ARG;
+    HeadP hp[3];
+    Work w[3];
+    int Gs[3];
+    for (int h = 0; h < nheads; ++h) {
+        if (!heads_host[h].logits || !heads_host[h].dlogits || !heads_host[h].metrics || !heads_host[h].anchors_host || heads_host[h].G < 1)
+            return CY_ERR_ARG;
+        Gs[h] = heads_host[h].G;
+    }
+    size_t zero_bytes;
+    (void)carve_multi(workspace, nheads, Gs, B, A, nT, w, &zero_bytes);
+    long max_cells = 0;
+    for (int h = 0; h < 3; ++h) {
+        const int q = h < nheads ? h : 0;        // unused slots repeat head 0 (grid.y = nheads: never selected)
+        const cy_head_in& in = heads_host[q];
+        const double stride = (double)img_size / (double)in.G;
+        HeadP& d = hp[h];
+        d.logits = in.logits; d.dlogits = in.dlogits; d.metrics = in.metrics;
+        d.G = in.G; d.row_offset = in.row_offset; d.stride = (float)stride;
+        d.cells = (long)B * A * in.G * in.G;
+        if (fill_anchors(d.an_dec, in.anchors_host, A, 4, stride) || fill_anchors(d.an, in.anchors_host, A, 4, stride)) return CY_ERR_ARG;
+        d.w = w[q];
+        if (d.cells > max_cells) max_cells = d.cells;
+    }
+    const dim3 gy(1, nheads);
+    if (out) {
+        const long total = max_cells;      // B * G * G * A of the largest head
+        const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(decode3_kernel, dim3(grid, nheads), dim3(256), 0, cy_s(s), hp[0], hp[1], hp[2], B, A, C, out, rows_total);
+    }
+    if (hipMemsetAsync(workspace, 0, zero_bytes, cy_s(s)) != hipSuccess) return -(1000 + 1);
+    const LossScales ls = {100.f, 1.f, 3.54f, 3.54f, 64.3f, 37.4f};  // reference yolo_layer.py:40-45
+    Scales sc;
+    if (use_giou) {
+        sc.gx = sc.gy = sc.gw = sc.gh = 0.f;
+        sc.geul = ls.leular; sc.gobj = ls.lobj; sc.gnoobj = ls.lobj; sc.gcls = ls.lcls;
+    } else {
+        sc.gx = sc.gy = sc.gw = sc.gh = 1.f;
+        sc.geul = 1.f; sc.gobj = ls.obj; sc.gnoobj = ls.noobj; sc.gcls = 1.f;
+    }
+    const int tb = (nT + 63) / 64;
+    if (nT > 0) {
+        const int ta = (nT + 64 / LPT - 1) / (64 / LPT);
+        hipLaunchKernelGGL(assign3_kernel, dim3(ta, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, B, A, ignore_thresh);
+        if (use_giou) {
+            hipLaunchKernelGGL(pairs3_kernel<true>, dim3(2 * tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, A, C, tb);
+            hipLaunchKernelGGL(pairs_finish3_kernel<true>, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, A, C);
+        } else {
+            hipLaunchKernelGGL(pairs3_kernel<false>, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, A, C, tb);
+            hipLaunchKernelGGL(pairs_finish3_kernel<false>, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, A, C);
+        }
+    }
+    const int grid = (int)((max_cells + 255) / 256 > 2048 ? 2048 : (max_cells + 255) / 256);
+    hipLaunchKernelGGL(dense3_kernel, dim3(grid, nheads), dim3(256), 0, cy_s(s), hp[0], hp[1], hp[2], targets, B, A, C, sc);
+    if (nT > 0 && use_giou)
+        hipLaunchKernelGGL(giou_grad3_kernel, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], nT, A, C, ls.lgiou / (float)nT);
+    hipLaunchKernelGGL(finalize3_kernel, gy, dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], nT, C, use_giou, ls);
+    CY_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int cy_yolo_loss(const float* logits, int B, int G, int A, int C, const float* targets, int nT,

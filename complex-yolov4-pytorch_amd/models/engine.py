@@ -107,6 +107,11 @@ class Engine:
         self.wpart = torch.empty(max(max_wpart, 1), **f32)
         self._pack_table = self._pack_key = self._pack_epoch = None
         self._in_side_head = self._heads_on_side = False
+        # the heads of a model as one batched sequence of launches (cy_yolo_loss_multi) when they share A, C and the threshold
+        same = len({(h['A'], h['C'], h['ignore_thresh']) for h in plan.heads}) == 1
+        self._multi_heads = (hasattr(ops, 'yolo_loss_multi') and same and 1 <= len(plan.heads) <= 3
+                             and os.environ.get('CY_HEADS_MULTI', '1') != '0' and getattr(device, 'type', str(device)) == 'cuda')
+        self._pending_heads, self._head_table = [], None
         self.fwd_serial = 0
         self._reduce_groups = None
         use_side = training and getattr(device, 'type', str(device)) == 'cuda' and os.environ.get('CY_WGRAD_SIDE_STREAM', '1') != '0'
@@ -356,6 +361,13 @@ class Engine:
             return
         h = rec['head']
         logits = self.act[rec['logits'].st.sid]
+        if (targets is not None and self._multi_heads and not self._in_side_head):
+            # training: the heads' decode + loss are batched into ONE sequence of launches issued at the last head (head =
+            # blockIdx.y: 9 launches per step instead of 8 per head -- their latency sits on the trunk's stream since round 3)
+            self._pending_heads.append(rec)
+            if len(self._pending_heads) == len(self.plan.heads):
+                self._run_heads(targets, use_giou, img_size)
+            return
         ops.yolo_decode(logits, self.N, rec['G'], rec['A'], rec['C'], rec['anchors'], img_size, self.outputs,
                         self.plan.rows_total, rec['row_offset'])
         if targets is None:
@@ -369,6 +381,25 @@ class Engine:
             dl = self.dlogits[h] = torch.empty(logits.numel(), dtype=torch.float32, device=self.device)
         ops.yolo_loss(logits, self.N, rec['G'], rec['A'], rec['C'], targets, rec['anchors'], img_size,
                       rec['ignore_thresh'], use_giou, self.loss_ws[h], self.metrics[h], dl)
+
+    def _run_heads(self, targets, use_giou, img_size):
+        recs, self._pending_heads = self._pending_heads, []
+        r0 = recs[0]
+        nT = targets.shape[0]
+        if self._head_table is None or self._head_table[2] < nT:
+            cap = max(nT, 64) if self._head_table is None else max(nT, 2 * self._head_table[2])     # room to grow: KITTI batches vary
+            need = ops.yolo_loss_multi_workspace([r['G'] for r in recs], self.N, r0['A'], r0['C'], cap)
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            heads = []
+            for r in recs:
+                h = r['head']
+                if self.dlogits[h] is None:
+                    self.dlogits[h] = torch.empty(self.act[r['logits'].st.sid].numel(), dtype=torch.float32, device=self.device)
+                heads.append((self.act[r['logits'].st.sid], self.dlogits[h], self.metrics[h], r['anchors'], r['G'], r['row_offset']))
+            self._head_table = (ops.make_head_table(heads), ws, cap)
+        table, ws, _ = self._head_table
+        ops.yolo_loss_multi(table, len(recs), self.N, r0['A'], r0['C'], targets, img_size, r0['ignore_thresh'], use_giou, ws,
+                            self.outputs, self.plan.rows_total)
 
     # ---- backward --------------------------------------------------------------------------------
     def backward(self, grads, gout_dev, loss_scale, on_module_done=None, act_scale=None):

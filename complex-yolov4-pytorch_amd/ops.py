@@ -526,6 +526,36 @@ def yolo_loss(logits, B, G, A, C, targets, anchors, img_size, ignore_thresh, use
                float(ignore_thresh), int(bool(use_giou)), _p(workspace), _p(metrics), _p(dlogits), _stream())
 
 
+class _HeadIn(ctypes.Structure):
+    _fields_ = [('logits', ctypes.c_void_p), ('dlogits', ctypes.c_void_p), ('metrics', ctypes.c_void_p), ('anchors', ctypes.c_void_p),
+                ('G', ctypes.c_int), ('row_offset', ctypes.c_int)]
+
+
+def yolo_loss_multi_workspace(Gs, B, A, C, nT):
+    return int(lib().raw('cy_yolo_loss_multi_workspace')(len(Gs), (ctypes.c_int * len(Gs))(*Gs), B, A, C, nT))
+
+
+def make_head_table(heads):
+    """heads: [(logits, dlogits, metrics, anchors [(w, h, im, re)] * A, G, row_offset)] -> the host table cy_yolo_loss_multi takes
+    (keeps the anchor arrays alive)."""
+    arr = (_HeadIn * len(heads))()
+    keep = []
+    for i, (logits, dlogits, metrics, anchors, G, row_offset) in enumerate(heads):
+        fa = _farr([v for a in anchors for v in a[:4]])
+        keep.append(fa)
+        arr[i].logits, arr[i].dlogits, arr[i].metrics = logits.data_ptr(), dlogits.data_ptr(), metrics.data_ptr()
+        arr[i].anchors = ctypes.cast(fa, ctypes.c_void_p).value
+        arr[i].G, arr[i].row_offset = int(G), int(row_offset)
+    return arr, keep
+
+
+def yolo_loss_multi(table, nheads, B, A, C, targets, img_size, ignore_thresh, use_giou, workspace, out, rows_total):
+    """Decode (out is not None) + loss of all heads in one sequence of launches (cy_yolo_loss_multi)."""
+    nT = 0 if targets is None else targets.shape[0]
+    lib().call('cy_yolo_loss_multi', nheads, ctypes.cast(table[0], ctypes.c_void_p), B, A, C, _p(targets) if nT else None, nT,
+               float(img_size), float(ignore_thresh), int(bool(use_giou)), _p(workspace), _p(out), rows_total, _stream())
+
+
 # ---- geometry / NMS ---------------------------------------------------------------------------------
 
 def riou_pairs(pred, target, giou):

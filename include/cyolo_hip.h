@@ -305,6 +305,18 @@ int cy_yolo_decode(const float* logits, int B, int G, int A, int C, const float*
 /* Scratch (private segment) bytes per lane of the per-target loss kernels in the loaded code object: 0 is the
  * precondition for running cy_yolo_loss concurrently with other kernels (side stream); -2 = no device to ask. */
 int cy_head_scratch_bytes(void);
+/* The heads of one model in ONE sequence of launches (head = blockIdx.y; decode when out != NULL, then the loss): what
+ * cy_yolo_decode + cy_yolo_loss do per head, with identical results, at 9 launches per step instead of 8 per head.  heads_host:
+ * host array of nheads (<= 3) entries; anchors_host: A * (w, h, im, re) in input pixels.  One workspace for all heads
+ * (cy_yolo_loss_multi_workspace bytes).  Replaces the three YoloLayer.forward calls of Darknet.forward (darknet2pytorch.py:218-226). */
+typedef struct {
+    const float* logits; float* dlogits; float* metrics; const float* anchors_host;
+    int G, row_offset;
+} cy_head_in;
+int64_t cy_yolo_loss_multi_workspace(int nheads, const int* Gs_host, int B, int A, int C, int nT);
+int cy_yolo_loss_multi(int nheads, const cy_head_in* heads_host, int B, int A, int C, const float* targets, int nT,
+                       float img_size, float ignore_thresh, int use_giou, void* workspace, float* out, int rows_total,
+                       cy_stream_t s);
 /* Workspace size in bytes for cy_yolo_loss. */
 int64_t cy_yolo_loss_workspace(int B, int G, int A, int C, int nT);
 /* Fused build_targets + loss + metrics + d(loss)/d(logits) (yolo_layer.py:69-142, :199-251, and the

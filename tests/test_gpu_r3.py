@@ -311,3 +311,44 @@ def test_graphed_train_step_equals_eager_steps():
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     for k, v in runs[0][1].items():
         assert torch.equal(v, runs[1][1][k]), k
+
+
+@pytest.mark.parametrize('giou', [True, False])
+def test_batched_heads_equal_per_head_calls(giou):
+    """cy_yolo_loss_multi (decode + loss of the three heads, head = blockIdx.y) against cy_yolo_decode + cy_yolo_loss per head on
+    the same logits and targets (collisions included): outputs, the 20 metrics and d(logits) of every head bit-identical."""
+    import complex_yolov4_pytorch_amd.ops as ops
+    B, A, C, S = 4, 3, 3, 608
+    anchors = [[(11, 14, -3.14, 1), (11, 14, 0, 1), (23, 51, 0.3, 0.9)], [(23, 51, -3.14, 1), (23, 51, 0, 1), (24, 60, 1, 0)],
+               [(27, 63, 0, 1), (29, 74, 0.2, 0.95), (29, 74, -1, 0.1)]]
+    Gs = [76, 38, 19]
+    g = torch.Generator().manual_seed(9)
+    logits = [(torch.randn(B * G * G * A * (7 + C), generator=g) * 0.6).to(DEV) for G in Gs]
+    tg = syn.targets(B, 7, S, seed=9, collide=True).to(DEV)
+    bad = tg[3:4].clone(); bad[0, 0] = -1                       # a rejected row (sample index out of range)
+    tg = torch.cat([tg, bad], 0).contiguous()
+    nT = tg.shape[0]
+    rows_total = A * sum(G * G for G in Gs)
+    offs = [0, A * Gs[0] ** 2, A * (Gs[0] ** 2 + Gs[1] ** 2)]
+    # per head
+    out1 = torch.zeros(B, rows_total, 7 + C, device=DEV)
+    met1 = [torch.zeros(20, device=DEV) for _ in Gs]
+    dl1 = [torch.empty_like(l) for l in logits]
+    for h, G in enumerate(Gs):
+        ops.yolo_decode(logits[h], B, G, A, C, anchors[h], S, out1, rows_total, offs[h])
+        ws = torch.empty(ops.yolo_loss_workspace(B, G, A, C, nT), dtype=torch.uint8, device=DEV)
+        ops.yolo_loss(logits[h], B, G, A, C, tg, anchors[h], S, 0.7, giou, ws, met1[h], dl1[h])
+    # batched
+    out2 = torch.zeros(B, rows_total, 7 + C, device=DEV)
+    met2 = [torch.zeros(20, device=DEV) for _ in Gs]
+    dl2 = [torch.empty_like(l) for l in logits]
+    table = ops.make_head_table([(logits[h], dl2[h], met2[h], anchors[h], Gs[h], offs[h]) for h in range(3)])
+    ws = torch.empty(ops.yolo_loss_multi_workspace(Gs, B, A, C, nT + 5), dtype=torch.uint8, device=DEV)
+    for _ in range(2):                                          # twice: the workspace is re-zeroed by the call itself
+        ops.yolo_loss_multi(table, 3, B, A, C, tg, S, 0.7, giou, ws, out2, rows_total)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2)
+    for h in range(3):
+        assert torch.equal(met1[h], met2[h]), (h, met1[h], met2[h])
+        assert torch.equal(dl1[h], dl2[h]), h
+    assert float(met1[0][19]) == 1.0                            # the rejected row is counted, not assigned
