@@ -420,6 +420,42 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
         __syncthreads();
     }
 
+    if constexpr (BCO == 128 && BCI == 128) {
+        // The slab tile leaves through LDS (the ring is free now): each wave transposes its 64 x 64 accumulator block into
+        // [row][col] fp32 rows (stride 68 words: the four row groups of a fragment land on disjoint banks) and stores 16 bytes
+        // per lane, 256 contiguous bytes per row -- 16 store instructions per lane instead of 64 four-byte ones in 64-byte
+        // runs.  (Atomic mode adds word by word as before.)
+        if (!p.atomic) {
+            constexpr int RS = 68;
+            float* wt = reinterpret_cast<float*>(smem) + wave * (32 * RS);
+            static_assert(4 * 32 * RS * 4 <= 2 * STAGE, "the four wave tiles (32 rows at a time) fit in the ring");
+            float* slab = p.part + (size_t)sp * p.CoRows * p.Ncols;
+            const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+            const int col = col0 + wj * 64 + c4;
+#pragma unroll
+            for (int h = 0; h < TI / 2; ++h) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) wt[(i * 16 + g * 4 + r) * RS + j * 16 + q16] = acc[2 * h + i][j][r];
+                // (wave-private tile: the wave's ds_writes are ordered before its ds_reads by lgkmcnt, no barrier)
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 4 + r0;
+                    const int co = co0 + wi * 64 + h * 32 + row;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wt + row * RS + c4);
+                    if (co >= p.CoRows || col >= p.Ncols) continue;
+                    float* dst = slab + (size_t)co * p.Ncols + col;
+                    if (col + 3 < p.Ncols && (p.Ncols & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+                    else
+                        for (int e = 0; e < 4 && col + e < p.Ncols; ++e) dst[e] = v[e];
+                }
+            }
+            return;
+        }
+    }
     wgrad_store<TI, TJ, BCO, BCI>(p, acc, sp, co0, col0, wi, wj, q16, g);
 }
 
@@ -461,8 +497,11 @@ int launch(const WgradParams& p, int split, hipStream_t s) {
 inline int tile_of(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
 
 template <typename T>
-int dispatch_dma(const WgradParams& p, int split, hipStream_t s) {
-    const int bco = tile_of(p.CoRows), bci = tile_of(p.Ncols);
+int dispatch_dma(const WgradParams& p, int split, int cap, hipStream_t s) {
+    // cap = 64: 64 x 64 tiles where 128 x 128 would be chosen -- four times the tiles, so a quarter of the split-K factor (and of
+    // the slab traffic) for the same number of blocks; the engine times both (layers with a small weight matrix and many pixels)
+    int bco = tile_of(p.CoRows), bci = tile_of(p.Ncols);
+    if (cap == 64) { if (bco > 64) bco = 64; if (bci > 64) bci = 64; }
 #define CY_WD(A, B) \
     if (bco == A && bci == B) return launch_dma<T, A, B>(p, split, s);
     CY_WD(128, 128) CY_WD(128, 64) CY_WD(128, 32) CY_WD(64, 128) CY_WD(64, 64) CY_WD(64, 32) CY_WD(32, 128) CY_WD(32, 64)
@@ -636,13 +675,14 @@ extern "C" int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int 
     p.pps = (((p.M + split - 1) / split) + bkp - 1) / bkp * bkp;
     p.x_bytes = 0;
     p.atomic = (use_tr & 4) ? 1 : 0;
+    const int cap = (use_tr & 8) ? 64 : 128;
     use_tr &= 3;
     if (dtype == CY_F32) return dispatch<float, false>(p, split, cy_s(s));
     {   // direct-to-LDS kernel; use_tr = 2 forces the register-staged kernel (A/B runs), as do offsets beyond 32 bits
         const size_t xb = (((size_t)N * XH * XW - 1) * ldx + Ci) * 2, ab = ((size_t)p.M + 128) * lddy * 2;
         if (use_tr == 1 && xb < 0xFFFFFF00ull && ab < 0xFFFFFF00ull && 64 / OW + 1 <= 2 * OH) {
             p.x_bytes = (unsigned)xb;
-            return dtype == CY_F16 ? dispatch_dma<f16>(p, split, cy_s(s)) : dispatch_dma<bf16>(p, split, cy_s(s));
+            return dtype == CY_F16 ? dispatch_dma<f16>(p, split, cap, cy_s(s)) : dispatch_dma<bf16>(p, split, cap, cy_s(s));
         }
     }
     if (dtype == CY_BF16) return use_tr ? dispatch<bf16, true>(p, split, cy_s(s)) : dispatch<bf16, false>(p, split, cy_s(s));

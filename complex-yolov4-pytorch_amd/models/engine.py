@@ -66,6 +66,7 @@ class Engine:
         max_wpart = 0
         self.wsplit, self.wslab_off, self.wsplit_cap = {}, {}, {}
         self.watomic = {}          # conv idx -> split-K factor of its ATOMIC weight-gradient launch (all splits add into ONE slab)
+        self.wtile64 = set()       # conv idx whose weight gradient runs on 64 x 64 tiles (a quarter of the split-K slabs)
         self._views, self._view_refs = {}, []
         self._wgrad_tuned = False
         for rec in plan.convs:
@@ -471,7 +472,7 @@ class Engine:
             if key not in memo:
                 s0, cap = self.wsplit[idx], self.wsplit_cap[idx]
                 hit = tune.get(key)
-                if hit is not None and 1 <= abs(int(hit[0])) <= max(cap, 512) and not (self.det and int(hit[0]) < 0):
+                if hit is not None and 1 <= abs(int(hit[0])) % 1000 <= max(cap, 512) and not (self.det and (int(hit[0]) < 0 or int(hit[0]) >= 1000)):
                     memo[key] = int(hit[0])
                     tune.put(key, *hit)
                 elif self.det and not _DET_TIMING:
@@ -485,26 +486,36 @@ class Engine:
                     off = self.wslab_off[idx]
                     # atomic mode (default mode only): every split adds into ONE resident slab -- the fold then reads a single
                     # slab and writes zeros back (2 slab passes whatever the split), and more splits cost no memory
-                    am = os.environ.get('CY_WGRAD_ATOMIC', '1')
-                    modes = [False] if (self.det or am == '0') else ([True] if am == '2' else [False, True])
-                    for atomic in modes:
-                        for c in (cands if not atomic else sorted(set(cands + [2 * cands[-1], 4 * cands[-1]]))):
+                    am = os.environ.get('CY_WGRAD_ATOMIC', '0')      # opt-in: measured no better than slabs
+                    modes = [(False, False)] if (self.det or am == '0') else ([(True, False)] if am == '2' else [(False, False), (True, False)])
+                    # 64 x 64 tiles for the 16-bit layers whose 128 x 128 tiling has few tiles and therefore a deep split: a
+                    # quarter of the slabs for the same number of blocks (choice encoded as split + 1000)
+                    if self.dt != CY_F32 and not self.det and s0 >= 8 and cop >= 128 and kk * cip >= 128 and os.environ.get('CY_WGRAD_TILE64', '1') != '0':
+                        modes.append((False, True))
+                    for atomic, t64 in modes:
+                        cl = cands if not atomic else sorted(set(cands + [2 * cands[-1], 4 * cands[-1]]))
+                        if t64:
+                            cl = sorted({max(1, c // 4) for c in cands} | {max(1, c // 3) for c in cands[:4]})
+                        for c in cl:
                             if (c - 1) * 512 >= dy.M and c > 1:
                                 continue
                             part = self.wpart[off:off + (1 if atomic else c) * cop * kk * cip]
-                            ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c, atomic=atomic)
+                            ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c, atomic=atomic, tile64=t64)
                             ev0.record()
                             for _ in range(reps):
-                                ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c, atomic=atomic)
+                                ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, c, atomic=atomic, tile64=t64)
                             ev1.record()
                             ev1.synchronize()
                             cost = ev0.elapsed_time(ev1) * 1e3 / reps + (2 if atomic else c) * slab_us
                             if best_cost is None or cost < best_cost:
-                                best, best_cost = (-c if atomic else c), cost
+                                best, best_cost = (-c if atomic else (c + 1000 if t64 else c)), cost
                     memo[key] = best
                     tune.put(key, best, best_cost * 1e-3)
             if memo[key] < 0:
                 self.watomic[idx], self.wsplit[idx] = -memo[key], 1
+            elif memo[key] >= 1000:
+                self.wtile64.add(idx)
+                self.wsplit[idx] = memo[key] - 1000
             else:
                 self.wsplit[idx] = memo[key]
         if self.watomic:
@@ -684,6 +695,8 @@ class Engine:
         with ops.prof('wgrad', *self._conv_work(rec)):
             if idx in self.watomic:
                 ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, self.watomic[idx], atomic=True)
+            elif idx in self.wtile64:
+                ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, sp, tile64=True)
             else:
                 ops.conv_wgrad(dy, xv, rec['ks'], rec['stride'], rec['pad'], part, sp)
 

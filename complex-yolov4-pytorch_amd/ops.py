@@ -374,11 +374,12 @@ def wgrad_split(M, Co, Ci, ks):
     return lib().raw('cy_conv_wgrad_split')(M, Co, Ci, ks)
 
 
-def conv_wgrad(dy, x, ks, stride, pad, part, split, use_tr=1, atomic=False):
-    """atomic: every split adds into slab 0 (pre-zeroed) with fp32 atomics instead of writing its own slab."""
+def conv_wgrad(dy, x, ks, stride, pad, part, split, use_tr=1, atomic=False, tile64=False):
+    """atomic: every split adds into slab 0 (pre-zeroed) with fp32 atomics instead of writing its own slab; tile64: tiles of at
+    most 64 x 64 (a quarter of the split for the same number of blocks)."""
     _require_gpu()
     lib().call('cy_conv_wgrad', _p(dy), dy.N, dy.H, dy.W, dy.C, dy.ld, _p(x), x.H, x.W, x.C, x.ld, ks, stride, pad,
-               dy.dt, _p(part), split, use_tr | (4 if atomic else 0), _stream())
+               dy.dt, _p(part), split, use_tr | (4 if atomic else 0) | (8 if tile64 else 0), _stream())
 
 
 def wgrad_reduce(part, split, co_rows, ci_pad, ks, Co, Ci, scale, accumulate, grad):

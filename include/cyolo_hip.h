@@ -194,7 +194,8 @@ int cy_bn_scratch_rows(void);
  * use_tr: 1 = the default kernels (LDS transpose reads), 0 / 2 = test / A-B variants; + 4 = ATOMIC mode: the pixel range is
  * still cut into `split` blocks per tile, but every block ADDS its tile into slab 0 with fp32 atomics (part must hold one
  * zeroed slab; fold it with split = 1 and cy_reduce_desc.flags bit 0).  No slab traffic proportional to `split`; the
- * sum's rounding depends on arrival order, so the deterministic mode never uses it. */
+ * sum's rounding depends on arrival order, so the deterministic mode never uses it.  + 8 = tiles of at most 64 x 64 (16-bit
+ * kernels): four times the tiles of the default 128 x 128, i.e. the same number of blocks at a quarter of the split. */
 int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int lddy, const void* x, int XH, int XW, int Ci,
                   int ldx, int ks, int stride, int pad, int dtype, float* part, int split, int use_tr, cy_stream_t s);
 /* Recommended split for the given problem (fills the chip, bounded slab memory). */
