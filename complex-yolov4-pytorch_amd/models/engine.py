@@ -113,6 +113,7 @@ class Engine:
         self._multi_heads = (hasattr(ops, 'yolo_loss_multi') and same and 1 <= len(plan.heads) <= 3
                              and os.environ.get('CY_HEADS_MULTI', '1') != '0' and getattr(device, 'type', str(device)) == 'cuda')
         self._pending_heads, self._head_table = [], None
+        self._wgrad_ev, self._main_stream, self._side_scope = {}, None, None
         self.fwd_serial = 0
         self._reduce_groups = None
         use_side = training and getattr(device, 'type', str(device)) == 'cuda' and os.environ.get('CY_WGRAD_SIDE_STREAM', '1') != '0'
@@ -256,12 +257,15 @@ class Engine:
     def _conv_work(self, rec):
         """(algorithmic flops, algorithmic bytes) of one pass of this conv: 2*M*Cout*k*k*Cin with the REAL channel
         counts, and input + output + weights each touched once in the storage dtype."""
-        M = self.N * rec['H'] * rec['W']
-        kk = rec['ks'] * rec['ks']
-        es = 4 if self.dt == ops.CY_F32 else 2
-        flops = 2.0 * M * rec['cout'] * kk * rec['cin']
-        nbytes = es * (self.N * rec['xH'] * rec['xW'] * rec['cin'] + M * rec['cout'] + rec['cout'] * kk * rec['cin'])
-        return flops, nbytes
+        cw = rec.get('_work')
+        if cw is None or cw[0] != (self.N, self.dt):
+            M = self.N * rec['H'] * rec['W']
+            kk = rec['ks'] * rec['ks']
+            es = 4 if self.dt == ops.CY_F32 else 2
+            flops = 2.0 * M * rec['cout'] * kk * rec['cin']
+            nbytes = es * (self.N * rec['xH'] * rec['xW'] * rec['cin'] + M * rec['cout'] + rec['cout'] * kk * rec['cin'])
+            cw = rec['_work'] = ((self.N, self.dt), (flops, nbytes))
+        return cw[1]
 
     def _names(self, rec):
         nm = rec.get('_names')
@@ -418,6 +422,9 @@ class Engine:
         if self._reduce_groups is None or self._reduce_key != grads[next(iter(grads))].data_ptr():
             self._build_reduce_groups()
         flush_at = {g['last']: g for g in self._reduce_groups}
+        if self.side is not None:
+            self._main_stream = torch.cuda.current_stream(self.device)
+            self._side_scope = ops.stream_scope(self.side)
         if self.bnpart_pair is not None:
             self._bp = 0
             self.bnpart_pair[0].zero_()
@@ -677,10 +684,15 @@ class Engine:
         is issued on a side HIP stream: its MFMA blocks fill the tails of, and run beside, the HBM-bound BN passes and
         the dgrad of the following layers on the main stream.  The fold of each group waits for the side stream."""
         if self.side is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+            # (host cost matters here: 110 of these per step.  One reusable event per conv; the launch goes to the side stream
+            # through the operator layer's stream scope alone -- no torch op runs inside, so torch's notion of the current
+            # stream does not have to follow)
+            ev = self._wgrad_ev.get(rec['idx'])
+            if ev is None:
+                ev = self._wgrad_ev[rec['idx']] = torch.cuda.Event()
+            ev.record(self._main_stream)
             self.side.wait_event(ev)
-            with torch.cuda.stream(self.side), ops.stream_scope(self.side):
+            with self._side_scope:
                 self._wgrad_launch(rec, dy, xv)
             return
         self._wgrad_launch(rec, dy, xv)
