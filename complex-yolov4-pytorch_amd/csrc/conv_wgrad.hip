@@ -575,6 +575,8 @@ __device__ __forceinline__ void fold_pairs(const cy_reduce_desc& d, long first_p
     if (p < npairs) {
         const int ci = (int)(p % d.Ci), co = (int)(p / d.Ci);
         const float* src = d.part + (size_t)co * ncols + ci;
+        // (four slabs' loads in flight per trip: the sums stay in slab order, acc[t] is one chain either way)
+#pragma unroll 4
         for (int sp = sl; sp < d.split; sp += lanes) {
 #pragma unroll
             for (int t = 0; t < KK; ++t) acc[t] += src[(size_t)sp * slab + t * d.CiPad];

@@ -449,9 +449,13 @@ __global__ void maxpool_rows_kernel(const T* __restrict__ x, int N, int H, int W
         int arg[CH];
 #pragma unroll
         for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; arg[e] = 0; }
-        for (int b = 0; b < k; ++b) {
-            const int w = ow * stride - pad + b;
-            if (w < 0 || w >= W) continue;
+        // (the tap range is clamped to the row instead of skipping taps inside the loop: a branch-free body lets the loads of
+        // several taps fly together -- the k = 13 pool of the SPP block used to pay 13 memory latencies back to back)
+        const int w0 = ow * stride - pad;
+        const int b_lo = w0 < 0 ? -w0 : 0, b_hi = W - w0 < k ? W - w0 : k;
+#pragma unroll 4
+        for (int b = b_lo; b < b_hi; ++b) {
+            const int w = w0 + b;
             float f[CH];
             chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(x + (nh * W + w) * ldx + ck * CH), f);
 #pragma unroll
@@ -478,9 +482,11 @@ __global__ void maxpool_cols_kernel(const T* __restrict__ m1, int N, int H, int 
         int arg[CH];
 #pragma unroll
         for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; arg[e] = 0; }
-        for (int a = 0; a < k; ++a) {
-            const int h = oh * stride - pad + a;
-            if (h < 0 || h >= H) continue;
+        const int h0 = oh * stride - pad;
+        const int a_lo = h0 < 0 ? -h0 : 0, a_hi = H - h0 < k ? H - h0 : k;
+#pragma unroll 4
+        for (int a = a_lo; a < a_hi; ++a) {
+            const int h = h0 + a;
             float f[CH];
             chunk_to_f32<T>(*reinterpret_cast<const u32x4*>(m1 + (((long)n * H + h) * OW + ow) * C + ck * CH), f);
 #pragma unroll
@@ -493,7 +499,7 @@ __global__ void maxpool_cols_kernel(const T* __restrict__ m1, int N, int H, int 
 }
 
 // backward pass 1: dm1[n][r][ow] = sum over the outputs (oh, ow) whose column pass selected row r
-template <typename T>
+template <typename T, bool S1>      // S1: stride 1 (the SPP pools), no divisibility test per tap
 __global__ void maxpool_bwd_cols_kernel(const T* __restrict__ dy, int N, int OH, int OW, int C, int lddy,
                                         const uint8_t* __restrict__ a1, float* __restrict__ dm1, int H, int k, int stride,
                                         int pad) {
@@ -507,11 +513,14 @@ __global__ void maxpool_bwd_cols_kernel(const T* __restrict__ dy, int N, int OH,
         float acc[CH];
 #pragma unroll
         for (int e = 0; e < CH; ++e) acc[e] = 0.f;
-        for (int a = 0; a < k; ++a) {
+        // taps whose output row exists: 0 <= t = r + pad - a < OH * stride
+        const int a_lo = r + pad - (OH * stride - 1) > 0 ? r + pad - (OH * stride - 1) : 0;
+        const int a_hi = r + pad < k - 1 ? r + pad : k - 1;
+#pragma unroll 4
+        for (int a = a_lo; a <= a_hi; ++a) {
             const int t = r + pad - a;
-            if (t < 0 || t % stride) continue;
-            const int oh = t / stride;
-            if (oh >= OH) continue;
+            if (!S1 && t % stride) continue;
+            const int oh = S1 ? t : t / stride;
             const long q = ((long)n * OH + oh) * OW + ow;
             int sel[CH];
             load_bytes<CH>(a1 + q * C + ck * CH, sel);
@@ -528,7 +537,7 @@ __global__ void maxpool_bwd_cols_kernel(const T* __restrict__ dy, int N, int OH,
 }
 
 // backward pass 2: dx[n][r][w] (+)= sum over the (r, ow) whose row pass selected column w
-template <typename T>
+template <typename T, bool S1>
 __global__ void maxpool_bwd_rows_kernel(const float* __restrict__ dm1, const uint8_t* __restrict__ b1, int N, int H, int OW,
                                         int C, T* __restrict__ dx, int W, int lddx, int k, int stride, int pad,
                                         int accumulate) {
@@ -543,17 +552,25 @@ __global__ void maxpool_bwd_rows_kernel(const float* __restrict__ dm1, const uin
         float acc[CH];
 #pragma unroll
         for (int e = 0; e < CH; ++e) acc[e] = 0.f;
-        for (int b = 0; b < k; ++b) {
+        const int b_lo = w + pad - (OW * stride - 1) > 0 ? w + pad - (OW * stride - 1) : 0;
+        const int b_hi = w + pad < k - 1 ? w + pad : k - 1;
+#pragma unroll 4
+        for (int b = b_lo; b <= b_hi; ++b) {
             const int t = w + pad - b;
-            if (t < 0 || t % stride) continue;
-            const int ow = t / stride;
-            if (ow >= OW) continue;
+            if (!S1 && t % stride) continue;
+            const int ow = S1 ? t : t / stride;
             const long q = (nr * OW + ow) * C + ck * CH;
             int sel[CH];
             load_bytes<CH>(b1 + q, sel);
+            float g[CH];     // whole 16-byte groups, unconditionally: the selects below cost nothing beside a dependent load
+#pragma unroll
+            for (int e4 = 0; e4 < CH; e4 += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(dm1 + q + e4);
+                g[e4] = v.x; g[e4 + 1] = v.y; g[e4 + 2] = v.z; g[e4 + 3] = v.w;
+            }
 #pragma unroll
             for (int e = 0; e < CH; ++e)
-                if (sel[e] == b) acc[e] += dm1[q + e];
+                if (sel[e] == b) acc[e] += g[e];
         }
         T* dst = dx + p * lddx + ck * CH;
         if (accumulate) {
@@ -629,6 +646,17 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int N, int C, i
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
         const long hw = (long)H * W;
         const long n = p / hw, r = p - n * hw;
+        if (CPad * (int)sizeof(T) == 16 && C <= 8) {
+            // the usual case (3 BEV channels padded to one 16-byte chunk): the planes' loads in flight together, one store
+            float f[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) f[c] = c < C ? x[(n * C + c) * hw + r] : 0.f;
+            T v[16 / sizeof(T)];
+#pragma unroll
+            for (int c = 0; c < (int)(16 / sizeof(T)); ++c) v[c] = (T)f[c];
+            *reinterpret_cast<u32x4*>(y + p * CPad) = *reinterpret_cast<const u32x4*>(v);
+            continue;
+        }
         for (int c = 0; c < CPad; ++c) y[p * CPad + c] = c < C ? (T)x[(n * C + c) * hw + r] : (T)0.f;
     }
 }
@@ -663,20 +691,44 @@ __device__ __forceinline__ void pack_tile(const cy_pack_desc& d, int tile, T* ld
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = 64 * kk;
     const bool vec = ((d.Ci * kk) & 3) == 0 && ci0 + 64 <= d.Ci;   // whole 16-byte groups of the master row are valid
-    for (int r = wave; r < 64; r += 4) {
-        const int co = co0 + r;
-        const float* src = d.w + ((long)co * d.Ci + ci0) * kk;
-        if (vec && co < d.Co) {
-            for (int j4 = lane * 4; j4 < seg; j4 += 256) {
-                const float4 v = *reinterpret_cast<const float4*>(src + j4);
-                const float f[4] = {v.x, v.y, v.z, v.w};
+    if (KK > 0 && vec) {
+        // the tile's 64 rows of 64 * kk floats as one list of float4 groups, NB of them requested back to back per thread
+        // before the first is scattered into LDS (one group per trip costs an HBM round trip per 16 bytes: 144 in a row for
+        // a 3x3 tile, which is what the 0.29 ms of round 2's pack were made of)
+        constexpr int KQ = KK > 0 ? KK : 1;
+        constexpr int G4 = 16 * KQ;              // float4 groups per row
+        constexpr int PER = 64 * G4 / 256;       // groups per thread: 4 * kk
+        constexpr int NB = PER % 12 == 0 ? 12 : 4;
+        static_assert(PER % NB == 0, "batches of loads");
+#pragma unroll 1
+        for (int b0 = 0; b0 < PER; b0 += NB) {
+            typedef float fx4 __attribute__((ext_vector_type(4)));
+            fx4 v[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int q = tid + 256 * (b0 + i), r = q / G4, j4 = (q - r * G4) * 4;
+                // (row index clamped, value masked after the load: no branch between the loads; address space 1 because the
+                // pointer comes out of the descriptor table and a flat load would also count against the LDS counter)
+                const int rc = co0 + r < d.Co ? co0 + r : d.Co - 1;
+                typedef __attribute__((address_space(1))) const fx4 gfx4;
+                v[i] = *(gfx4*)(d.w + ((long)rc * d.Ci + ci0) * KQ + j4);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int q = tid + 256 * (b0 + i), r = q / G4, j4 = (q - r * G4) * 4;
+                const float keep = co0 + r < d.Co ? 1.f : 0.f;
+                const float f[4] = {v[i].x * keep, v[i].y * keep, v[i].z * keep, v[i].w * keep};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int j = j4 + e, ci_l = j / kk, tap = j - ci_l * kk;
+                    const int j = j4 + e, ci_l = j / KQ, tap = j - ci_l * KQ;
                     lds[r * ROW + tap * 64 + ci_l] = (T)f[e];
                 }
             }
-        } else {
+        }
+    } else {
+        for (int r = wave; r < 64; r += 4) {
+            const int co = co0 + r;
+            const float* src = d.w + ((long)co * d.Ci + ci0) * kk;
             for (int j = lane; j < seg; j += 64) {
                 const int ci_l = j / kk, tap = j - ci_l * kk;
                 const float v = (co < d.Co && ci0 + ci_l < d.Ci) ? src[j] : 0.f;
@@ -1168,12 +1220,14 @@ extern "C" int cy_maxpool_bwd(const void* dy, int N, int OH, int OW, int C, int 
     const uint8_t* b1 = argmax + (size_t)N * OH * OW * C;
     const int g1 = grid_for((long)N * H * OW * (C / ch));
     const int g2 = grid_for((long)N * H * W * (C / ch));
-#define CY_MB(T)                                                                                                          \
-    hipLaunchKernelGGL((maxpool_bwd_cols_kernel<T>), dim3(g1), dim3(256), 0, cy_s(s), (const T*)dy, N, OH, OW, C, lddy, a1,  \
-                       scratch, H, k, stride, pad);                                                                       \
-    hipLaunchKernelGGL((maxpool_bwd_rows_kernel<T>), dim3(g2), dim3(256), 0, cy_s(s), (const float*)scratch, b1, N, H, OW, C, \
+#define CY_MB2(T, S1_)                                                                                                        \
+    hipLaunchKernelGGL((maxpool_bwd_cols_kernel<T, S1_>), dim3(g1), dim3(256), 0, cy_s(s), (const T*)dy, N, OH, OW, C, lddy, a1,  \
+                       scratch, H, k, stride, pad);                                                                            \
+    hipLaunchKernelGGL((maxpool_bwd_rows_kernel<T, S1_>), dim3(g2), dim3(256), 0, cy_s(s), (const float*)scratch, b1, N, H, OW, C, \
                        (T*)dx, W, lddx, k, stride, pad, accumulate);
+#define CY_MB(T) if (stride == 1) { CY_MB2(T, true) } else { CY_MB2(T, false) }
     CY_DT_SWITCH(dtype, CY_MB)
+#undef CY_MB2
 #undef CY_MB
     CY_LAUNCH_CHECK();
     return 0;

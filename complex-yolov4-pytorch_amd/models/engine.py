@@ -92,14 +92,19 @@ class Engine:
                 self.wslab_off[rec['idx']] = max_wpart
                 max_wpart += self.wsplit_cap[rec['idx']] * cop * kk * cip
         # binned-atomics tables: zero once, every finaliser leaves its table zeroed for the next layer
-        self.stats = torch.zeros(max_stats, **f32)
-        self.bnpart = torch.zeros(max_bnrows, **f32)
+        # (the first statistics table and both BN-backward tables share one allocation: a training step zeroes them with ONE
+        # fill at the top of the forward pass -- nothing touches the backward tables before the backward pass)
+        _r64 = lambda n: (n + 63) // 64 * 64
+        self._ztab = torch.zeros(_r64(max_stats) + 2 * _r64(max_bnrows), **f32)
+        self.stats = self._ztab[:max_stats]
+        self.bnpart = self._ztab[_r64(max_stats):_r64(max_stats) + max_bnrows]
         # default (non-deterministic) mode: the fold runs in the prologue of the consuming kernel (cy_bn_act_fwd_fused /
         # cy_bn_act_bwd_apply_fused), which cannot zero the table it reads -- two tables alternate from layer to layer and
         # every launch zeroes the other one
         self.fused_bn = not self.det and hasattr(ops, 'bn_act_fwd_fused') and os.environ.get('CY_FUSED_BN', '1') != '0'
         self.stats_pair = [self.stats, torch.zeros(max_stats, **f32)] if self.fused_bn else None
-        self.bnpart_pair = [self.bnpart, torch.zeros(max_bnrows, **f32)] if (self.fused_bn and training) else None
+        self.bnpart_pair = ([self.bnpart, self._ztab[_r64(max_stats) + _r64(max_bnrows):][:max_bnrows]]
+                            if (self.fused_bn and training) else None)
         self._sp = self._bp = 0
         self.dgs, self.dbs = torch.empty(max_c, **f32), torch.empty(max_c, **f32)
         # deterministic mode: second-stage table of the two-stage folds (<= 256 rows) / partial rows of the head bias gradient
@@ -172,7 +177,8 @@ class Engine:
             # the alternating statistics tables restart from a defined state every pass (complex_yolov4.cfg has an ODD number of
             # BatchNorm layers: the parity used to carry over from step to step, which a captured and replayed step cannot do)
             self._sp = 0
-            self.stats_pair[0].zero_()
+            (self._ztab if self.bnpart_pair is not None else self.stats_pair[0]).zero_()
+            self._bn_tables_fwd = self.fwd_serial
         with self._scope():
             ops.nchw_to_nhwc(x, plan.input.C, self.dt, out=self.view(plan.input))
             self.params = params
@@ -427,8 +433,10 @@ class Engine:
             self._side_scope = ops.stream_scope(self.side)
         if self.bnpart_pair is not None:
             self._bp = 0
-            self.bnpart_pair[0].zero_()
-            self.bnpart_pair[1].zero_()
+            if getattr(self, '_bn_tables_fwd', -1) != self.fwd_serial:     # (zeroed by this step's forward pass otherwise)
+                self.bnpart_pair[0].zero_()
+                self.bnpart_pair[1].zero_()
+            self._bn_tables_fwd = -1
         with self._scope():
             for rec in self.plan.bwd:
                 getattr(self, '_b_' + rec['op'])(rec)
