@@ -123,16 +123,25 @@ __device__ __forceinline__ float cy_exp(float x) { return FAST ? __expf(x) : exp
 template <bool FAST>
 __device__ __forceinline__ float cy_div(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
 
+// Both functions are written branch-free (argument clamped at the threshold, result selected): an early return compiles to one
+// exec-mask region per ELEMENT (s_and_saveexec / s_cbranch_execz around each exp -> rcp chain), which serialises the eight
+// elements of a 16-byte chunk and keeps the compiler from pairing them into packed f32 instructions -- the BN-backward reduce
+// pass and the dgrad sums epilogue are VALU-bound on exactly this code.  Values are unchanged for every input: below the
+// threshold the clamp is the identity, above it the select returns what the early return did, NaN stays NaN (x > 20 is false
+// for it, so the clamp passes it through).
 template <bool FAST>
 __device__ __forceinline__ float mish_f(float x) {
-    if (x > 20.f) return x;
-    const float n = cy_exp<FAST>(x);
+    const bool big = x > 20.f;
+    const float xc = big ? 20.f : x;
+    const float n = cy_exp<FAST>(xc);
     const float w = n * (n + 2.f);
-    return x * cy_div<FAST>(w, w + 2.f);
+    const float r = xc * cy_div<FAST>(w, w + 2.f);
+    return big ? x : r;
 }
 template <bool FAST>
-__device__ __forceinline__ float mish_grad(float x) {
-    if (x > 20.f) return 1.f;
+__device__ __forceinline__ float mish_grad(float x0) {
+    const bool big = x0 > 20.f;
+    const float x = big ? 20.f : x0;
     const float n = cy_exp<FAST>(x);
     const float w = n * (n + 2.f);
     if (FAST) {
@@ -140,11 +149,13 @@ __device__ __forceinline__ float mish_grad(float x) {
         // sigmoid = n / (n + 1)  =>  mish' = (w v + 4 x n (n + 1)) / v^2   (v^2 <= 5e34 for x <= 20: no overflow).
         // The backward reduce pass is VALU-bound on this function.
         const float v = w + 2.f;
-        return (w * v + 4.f * x * n * (n + 1.f)) * __builtin_amdgcn_rcpf(v * v);
+        const float r = (w * v + 4.f * x * n * (n + 1.f)) * __builtin_amdgcn_rcpf(v * v);
+        return big ? 1.f : r;
     }
     const float t = cy_div<FAST>(w, w + 2.f);    // tanh(softplus(x))
     const float sg = cy_div<FAST>(n, 1.f + n);   // sigmoid(x)
-    return t + x * (1.f - t * t) * sg;
+    const float r = t + x * (1.f - t * t) * sg;
+    return big ? 1.f : r;
 }
 template <int ACT, bool FAST = false>
 __device__ __forceinline__ float act_f(float z) {

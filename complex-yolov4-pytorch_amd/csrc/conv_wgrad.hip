@@ -279,8 +279,12 @@ __device__ __forceinline__ int wg_key(int row) {
     else return (row >> 3) & 1;
 }
 
-template <typename T, int BCO, int BCI>
-__global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) {
+// LD = 1: four extra waves (one per SIMD) issue every DMA piece and carry the pixel bookkeeping of the tap-shifted X rows; the four
+// compute waves only read fragments and issue MFMAs.  (In the 4-wave form a wave spends ~100 cycles issuing each of its 8 pieces
+// per 64-pixel step against 512 cycles of MFMAs: with two blocks per CU the MFMA pipe cannot exceed ~40 % -- rocprofv3 counted
+// 27-33 %.)  Two blocks per CU in both forms (64 KB of LDS each; LD = 1 needs <= 128 VGPRs).
+template <typename T, int BCO, int BCI, int LD = 0>
+__global__ void __launch_bounds__(256 + 256 * LD, LD ? 4 : 2) wgrad_dma_kernel(const WgradParams p) {
     constexpr int BKP = 64;
     constexpr int RBA = BCO * 2, RBB = BCI * 2;          // row bytes
     constexpr int CPA = RBA / 16, CPB = RBB / 16;        // 16-byte chunks per row
@@ -291,7 +295,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
     static_assert(NPA >= 1 && NPB >= 1, "tile too narrow");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = LD && wave_all >= 4;          // wave-uniform role
+    const bool stages = !LD || is_loader;
+    const int wave = wave_all & 3;                       // index within the role
     const int wi = wave & 1, wj = wave >> 1;
     int lid;
     {
@@ -303,73 +311,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
     const int col0 = ct * BCI, co0 = (rest % p.nco_tiles) * BCO, sp = rest / p.nco_tiles;
     const int pix_begin = sp * p.pps;
     const int pix_end = min(p.M, pix_begin + p.pps);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    // descriptors: dY is cut at the end of this block's pixel range (rows beyond it read as zero)
-    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)pix_end * (unsigned)p.lddy * 2u, 0x00020000);
-    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-
-    // ---- A pieces (dY): piece k of this wave = tile rows (wave + 4k) * RPA + lane / CPA ----------------------------
-    unsigned a_off[NPA];
-#pragma unroll
-    for (int k = 0; k < NPA; ++k) {
-        const int row = (wave + 4 * k) * RPA + lane / CPA;
-        const int lchunk = (lane % CPA) ^ (wg_key<RBA>(row) << 1);
-        const int co = co0 + lchunk * 8;
-        a_off[k] = co < p.Co ? ((unsigned)(pix_begin + row) * (unsigned)p.lddy + (unsigned)co) * 2u : 0xFFFFFFFFu;
-    }
-    const unsigned a_step = (unsigned)BKP * (unsigned)p.lddy * 2u;
-    // ---- B pieces (X shifted by the tap of the lane's column): pixel bookkeeping per piece -----------------------------
-    int bn[NPB], boh[NPB], bow[NPB], b_dh[NPB], b_dw[NPB];
-    unsigned b_ci[NPB];
-    bool b_cok[NPB];
-    const int ohw = p.OH * p.OW;
-#pragma unroll
-    for (int k = 0; k < NPB; ++k) {
-        const int row = (wave + 4 * k) * RPB + lane / CPB;
-        const int lchunk = (lane % CPB) ^ (wg_key<RBB>(row) << 1);
-        const int col = col0 + lchunk * 8;
-        b_cok[k] = col < p.Ncols;
-        const int tap = b_cok[k] ? col / p.Ci : 0;
-        b_ci[k] = (unsigned)(col - tap * p.Ci) * 2u;
-        const int kh = tap / p.ks;
-        b_dh[k] = kh - p.pad;
-        b_dw[k] = tap - kh * p.ks - p.pad;
-        const int m = pix_begin + row;
-        const int n = m / ohw, rem = m - n * ohw;
-        bn[k] = n; boh[k] = rem / p.OW; bow[k] = rem - boh[k] * p.OW;
-    }
-    const unsigned pixb = (unsigned)p.ldx * 2u;
-    const int adv_h = BKP / p.OW, adv_w = BKP - adv_h * p.OW;
-
-    auto load_tile = [&](int kt, int stage) {
-        unsigned char* as_w = smem + stage * STAGE + wave_u * 1024;
-        unsigned char* bs_w = smem + stage * STAGE + BKP * RBA + wave_u * 1024;
-#pragma unroll
-        for (int k = 0; k < NPA; ++k) {
-            const unsigned v = a_off[k];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(as_w + k * 4096), 16, v, 0, 0, 0);
-            a_off[k] = v == 0xFFFFFFFFu ? v : v + a_step;
-        }
-#pragma unroll
-        for (int k = 0; k < NPB; ++k) {
-            const int m = pix_begin + kt * BKP + (wave + 4 * k) * RPB + lane / CPB;
-            const int xh = boh[k] * p.stride + b_dh[k], xw = bow[k] * p.stride + b_dw[k];
-            const bool ok = b_cok[k] & (m < pix_end) & ((unsigned)xh < (unsigned)p.XH) & ((unsigned)xw < (unsigned)p.XW);
-            const unsigned v = ok ? (unsigned)((bn[k] * p.XH + xh) * p.XW + xw) * pixb + b_ci[k] : 0xFFFFFFFFu;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(bs_w + k * 4096), 16, v, 0, 0, 0);
-            // advance the row's pixel by BKP = adv_h * OW + adv_w without loops (the host guarantees adv_h + 1 <= 2 * OH)
-            bow[k] += adv_w;
-            const bool cw = bow[k] >= p.OW;
-            bow[k] -= cw ? p.OW : 0;
-            boh[k] += adv_h + (cw ? 1 : 0);
-            const bool c1 = boh[k] >= p.OH;
-            boh[k] -= c1 ? p.OH : 0;
-            const bool c2 = boh[k] >= p.OH;
-            boh[k] -= c2 ? p.OH : 0;
-            bn[k] += (c1 ? 1 : 0) + (c2 ? 1 : 0);
-        }
-    };
+    const int wave_u = wave;
 
     // ---- MFMA-phase LDS addresses: per-lane constants (the swizzle key of the rows a lane reads does not depend on kk) ----
     const int q16 = lane & 15, g = lane >> 4;
@@ -393,11 +335,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = pix_end > pix_begin ? (pix_end - pix_begin + BKP - 1) / BKP : 0;
-    if (nkt > 0) load_tile(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1, cur ^ 1);
+    auto mma_tile = [&](int cur) {
         const unsigned char* st = smem + cur * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BKP / 32; ++kk) {
@@ -417,7 +355,91 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) acc[i][j] = WMma<T>::mma(a[i], b[j], acc[i][j]);
         }
+    };
+    if (stages) {
+        // (everything the DMA issue needs lives in this scope: in the LD form the compute waves never hold it in registers)
+        // descriptors: dY is cut at the end of this block's pixel range (rows beyond it read as zero)
+        const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)pix_end * (unsigned)p.lddy * 2u, 0x00020000);
+        const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+        // ---- A pieces (dY): piece k of this wave = tile rows (wave + 4k) * RPA + lane / CPA ----------------------------
+        unsigned a_off[NPA];
+    #pragma unroll
+        for (int k = 0; k < NPA; ++k) {
+            const int row = (wave + 4 * k) * RPA + lane / CPA;
+            const int lchunk = (lane % CPA) ^ (wg_key<RBA>(row) << 1);
+            const int co = co0 + lchunk * 8;
+            a_off[k] = co < p.Co ? ((unsigned)(pix_begin + row) * (unsigned)p.lddy + (unsigned)co) * 2u : 0xFFFFFFFFu;
+        }
+        const unsigned a_step = (unsigned)BKP * (unsigned)p.lddy * 2u;
+        // ---- B pieces (X shifted by the tap of the lane's column): pixel bookkeeping per piece -----------------------------
+        int bn[NPB], boh[NPB], bow[NPB], b_dh[NPB], b_dw[NPB];
+        unsigned b_ci[NPB];
+        bool b_cok[NPB];
+        const int ohw = p.OH * p.OW;
+    #pragma unroll
+        for (int k = 0; k < NPB; ++k) {
+            const int row = (wave + 4 * k) * RPB + lane / CPB;
+            const int lchunk = (lane % CPB) ^ (wg_key<RBB>(row) << 1);
+            const int col = col0 + lchunk * 8;
+            b_cok[k] = col < p.Ncols;
+            const int tap = b_cok[k] ? col / p.Ci : 0;
+            b_ci[k] = (unsigned)(col - tap * p.Ci) * 2u;
+            const int kh = tap / p.ks;
+            b_dh[k] = kh - p.pad;
+            b_dw[k] = tap - kh * p.ks - p.pad;
+            const int m = pix_begin + row;
+            const int n = m / ohw, rem = m - n * ohw;
+            bn[k] = n; boh[k] = rem / p.OW; bow[k] = rem - boh[k] * p.OW;
+        }
+        const unsigned pixb = (unsigned)p.ldx * 2u;
+        const int adv_h = BKP / p.OW, adv_w = BKP - adv_h * p.OW;
+
+        auto load_tile = [&](int kt, int stage) {
+            unsigned char* as_w = smem + stage * STAGE + wave_u * 1024;
+            unsigned char* bs_w = smem + stage * STAGE + BKP * RBA + wave_u * 1024;
+    #pragma unroll
+            for (int k = 0; k < NPA; ++k) {
+                const unsigned v = a_off[k];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(as_w + k * 4096), 16, v, 0, 0, 0);
+                a_off[k] = v == 0xFFFFFFFFu ? v : v + a_step;
+            }
+    #pragma unroll
+            for (int k = 0; k < NPB; ++k) {
+                const int m = pix_begin + kt * BKP + (wave + 4 * k) * RPB + lane / CPB;
+                const int xh = boh[k] * p.stride + b_dh[k], xw = bow[k] * p.stride + b_dw[k];
+                const bool ok = b_cok[k] & (m < pix_end) & ((unsigned)xh < (unsigned)p.XH) & ((unsigned)xw < (unsigned)p.XW);
+                const unsigned v = ok ? (unsigned)((bn[k] * p.XH + xh) * p.XW + xw) * pixb + b_ci[k] : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(bs_w + k * 4096), 16, v, 0, 0, 0);
+                // advance the row's pixel by BKP = adv_h * OW + adv_w without loops (the host guarantees adv_h + 1 <= 2 * OH)
+                bow[k] += adv_w;
+                const bool cw = bow[k] >= p.OW;
+                bow[k] -= cw ? p.OW : 0;
+                boh[k] += adv_h + (cw ? 1 : 0);
+                const bool c1 = boh[k] >= p.OH;
+                boh[k] -= c1 ? p.OH : 0;
+                const bool c2 = boh[k] >= p.OH;
+                boh[k] -= c2 ? p.OH : 0;
+                bn[k] += (c1 ? 1 : 0) + (c2 ? 1 : 0);
+            }
+        };
+
+
+        if (nkt > 0) load_tile(0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) load_tile(kt + 1, cur ^ 1);
+            if constexpr (!LD) mma_tile(cur);
+            __syncthreads();
+        }
+        if constexpr (LD) return;     // (the epilogue below has no block-wide barrier)
+    } else {
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            mma_tile(kt & 1);
+            __syncthreads();
+        }
     }
 
     if constexpr (BCO == 128 && BCI == 128) {
@@ -459,19 +481,19 @@ __global__ void __launch_bounds__(256, 2) wgrad_dma_kernel(const WgradParams p) 
     wgrad_store<TI, TJ, BCO, BCI>(p, acc, sp, co0, col0, wi, wj, q16, g);
 }
 
-template <typename T, int BCO, int BCI>
+template <typename T, int BCO, int BCI, int LD = 0>
 int launch_dma(const WgradParams& p, int split, hipStream_t s) {
     constexpr int smem = 2 * 64 * (BCO * 2 + BCI * 2);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, BCO, BCI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, BCO, BCI, LD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     WgradParams q = p;
     q.ncol_tiles = (p.Ncols + BCI - 1) / BCI;
     q.nco_tiles = (p.CoRows + BCO - 1) / BCO;
-    hipLaunchKernelGGL((wgrad_dma_kernel<T, BCO, BCI>), dim3(q.ncol_tiles * q.nco_tiles * split), dim3(256), smem, s, q);
+    hipLaunchKernelGGL((wgrad_dma_kernel<T, BCO, BCI, LD>), dim3(q.ncol_tiles * q.nco_tiles * split), dim3(256 + 256 * LD), smem, s, q);
     CY_LAUNCH_CHECK();
     return 0;
 }
@@ -502,6 +524,16 @@ int dispatch_dma(const WgradParams& p, int split, int cap, hipStream_t s) {
     // the slab traffic) for the same number of blocks; the engine times both (layers with a small weight matrix and many pixels)
     int bco = tile_of(p.CoRows), bci = tile_of(p.Ncols);
     if (cap == 64) { if (bco > 64) bco = 64; if (bci > 64) bci = 64; }
+    // CY_WGRAD_LOADERS: 0 = four self-staging waves everywhere, 1 = loader waves for the 128 x 128 tile only, 2 (default) = for every
+    // tile with at least 64 channels on both sides (measured on one box: 821 -> 830 -> 832 images/s for 0 / 1 / 2)
+    static int loaders = -1;
+    if (loaders < 0) { const char* e = getenv("CY_WGRAD_LOADERS"); loaders = e ? atoi(e) : 2; }
+    if (loaders && bco == 128 && bci == 128) return launch_dma<T, 128, 128, 1>(p, split, s);
+    if (loaders >= 2) {
+        if (bco == 128 && bci == 64) return launch_dma<T, 128, 64, 1>(p, split, s);
+        if (bco == 64 && bci == 128) return launch_dma<T, 64, 128, 1>(p, split, s);
+        if (bco == 64 && bci == 64) return launch_dma<T, 64, 64, 1>(p, split, s);
+    }
 #define CY_WD(A, B) \
     if (bco == A && bci == B) return launch_dma<T, A, B>(p, split, s);
     CY_WD(128, 128) CY_WD(128, 64) CY_WD(128, 32) CY_WD(64, 128) CY_WD(64, 64) CY_WD(64, 32) CY_WD(32, 128) CY_WD(32, 64)
