@@ -938,6 +938,12 @@ inline bool rowmap_ok(int C, int ch) {
     return C % ch == 0 && cpr >= 1 && cpr <= 256 && (256 % cpr) == 0;
 }
 
+inline long bn_blocks() {     // target number of pixel blocks of the fused BN passes (CY_BN_BLOCKS; measured on one box: 1024 -> 844, 4096 -> 846, 8192 / 16384 -> 848-849 images/s)
+    static long n = 0;
+    if (!n) { const char* e = getenv("CY_BN_BLOCKS"); n = e ? atol(e) : 8192; if (n < 64) n = 64; }
+    return n;
+}
+
 inline int ppb_for(long M, int C, int ch) {
     // pixels per block: aim at ~2048 blocks, at least 4 passes per thread row
     const int rpp = 256 / (C / ch);
@@ -996,7 +1002,7 @@ extern "C" int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, con
     const int cg = fused_cg(C, ch);
     if (cg < ch || cg > 128) return CY_ERR_ARG;
     const int rpp = 256 / (cg / ch);
-    long ppb = (M + 1023) / 1024;                 // ~1024 pixel blocks x C / CG channel groups
+    long ppb = (M + bn_blocks() - 1) / bn_blocks();                 // ~1024 pixel blocks x C / CG channel groups
     if (ppb < 4L * rpp) ppb = 4L * rpp;
     ppb = (ppb + rpp - 1) / rpp * rpp;
     const dim3 grid((unsigned)((M + ppb - 1) / ppb), (unsigned)(C / cg));
@@ -1033,7 +1039,7 @@ extern "C" int cy_bn_act_bwd_apply_fused(const void* x, int ldx, const void* dy,
     const int cg = fused_cg(C, ch);
     if (cg < ch || cg > 128) return CY_ERR_ARG;
     const int rpp = 256 / (cg / ch);
-    long ppb = (M + 1023) / 1024;
+    long ppb = (M + bn_blocks() - 1) / bn_blocks();
     if (ppb < 4L * rpp) ppb = 4L * rpp;
     ppb = (ppb + rpp - 1) / rpp * rpp;
     const dim3 grid((unsigned)((M + ppb - 1) / ppb), (unsigned)(C / cg));
