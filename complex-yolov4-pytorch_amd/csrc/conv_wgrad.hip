@@ -283,24 +283,34 @@ __device__ __forceinline__ int wg_key(int row) {
 // compute waves only read fragments and issue MFMAs.  (In the 4-wave form a wave spends ~100 cycles issuing each of its 8 pieces
 // per 64-pixel step against 512 cycles of MFMAs: with two blocks per CU the MFMA pipe cannot exceed ~40 % -- rocprofv3 counted
 // 27-33 %.)  Two blocks per CU in both forms (64 KB of LDS each; LD = 1 needs <= 128 VGPRs).
-template <typename T, int BCO, int BCI, int LD = 0>
-__global__ void __launch_bounds__(256 + 256 * LD, LD ? 4 : 2) wgrad_dma_kernel(const WgradParams p) {
-    constexpr int BKP = 64;
+// NST > 2 (with LD = 1): a ring of NST stages of BKP_ pixels with COUNTED vmcnt -- the loaders keep two tiles in flight across
+// every barrier instead of waiting for the tile they just issued (the protocol of conv_pipe.hip's loader variant); 4 stages of 32
+// pixels take the same 64 KB as 2 stages of 64, so two blocks per CU remain.
+// NCW = 8 (with LD = 1, NST = 3): eight compute waves, 4 over channels x 2 over columns, each on the same 64 x 64 block as in
+// the 4-wave forms -- a 256 x 128 block tile, ONE block per CU (144 KB of LDS).  The 128 x 128 tile needs 64 B/clk of L2 -> LDS
+// traffic per CU at full MFMA rate, which is all a CU's load path delivers; 256 x 128 needs 48.
+template <typename T, int BCO, int BCI, int LD = 0, int BKP_ = 64, int NST = 2, int NCW = 4>
+__global__ void __launch_bounds__(64 * NCW + 256 * LD, NCW == 8 ? 3 : (LD ? 4 : 2)) wgrad_dma_kernel(const WgradParams p) {
+    constexpr int BKP = BKP_;
+    constexpr int WCO = (NCW == 8 && BCO == 256) ? 4 : 2;    // compute waves over the output channels ...
+    constexpr int WCI = NCW / WCO;                           // ... and over the (tap, ci) columns
+    static_assert(NST == 2 || (LD == 1 && (NST == 3 || NST == 4)), "ring variants");
+    static_assert(NCW == 4 || (NCW == 8 && LD == 1 && NST > 2 && ((BCO == 256 && BCI == 128) || (BCO == 128 && BCI == 256))), "8-wave variants");
     constexpr int RBA = BCO * 2, RBB = BCI * 2;          // row bytes
     constexpr int CPA = RBA / 16, CPB = RBB / 16;        // 16-byte chunks per row
     constexpr int RPA = 64 / CPA, RPB = 64 / CPB;        // rows per 1 KB piece
     constexpr int NPA = BKP / RPA / 4, NPB = BKP / RPB / 4;  // pieces per wave and K step
     constexpr int STAGE = BKP * (RBA + RBB);
-    constexpr int TI = BCO / 32, TJ = BCI / 32;
+    constexpr int TI = BCO / (16 * WCO), TJ = BCI / (16 * WCI);
     static_assert(NPA >= 1 && NPB >= 1, "tile too narrow");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_loader = LD && wave_all >= 4;          // wave-uniform role
+    const bool is_loader = LD && wave_all >= NCW;        // wave-uniform role
     const bool stages = !LD || is_loader;
-    const int wave = wave_all & 3;                       // index within the role
-    const int wi = wave & 1, wj = wave >> 1;
+    const int wave = is_loader ? wave_all - NCW : wave_all;   // index within the role (loaders: 0..3)
+    const int wi = wave % WCO, wj = wave / WCO;
     int lid;
     {
         const int nblk = gridDim.x, bid = blockIdx.x;
@@ -319,12 +329,12 @@ __global__ void __launch_bounds__(256 + 256 * LD, LD ? 4 : 2) wgrad_dma_kernel(c
     unsigned a_col[TI], b_col[TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        const int cbyte = (wi * (BCO / 2) + i * 16 + ((q16 & 3) << 2)) * 2;
+        const int cbyte = (wi * (BCO / WCO) + i * 16 + ((q16 & 3) << 2)) * 2;
         a_col[i] = (unsigned)(prow0 * RBA + ((((cbyte >> 4) ^ (wg_key<RBA>(prow0) << 1)) << 4) | (cbyte & 15)));
     }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-        const int cbyte = (wj * (BCI / 2) + j * 16 + ((q16 & 3) << 2)) * 2;
+        const int cbyte = (wj * (BCI / WCI) + j * 16 + ((q16 & 3) << 2)) * 2;
         b_col[j] = (unsigned)(BKP * RBA + prow0 * RBB + ((((cbyte >> 4) ^ (wg_key<RBB>(prow0) << 1)) << 4) | (cbyte & 15)));
     }
 
@@ -364,7 +374,7 @@ __global__ void __launch_bounds__(256 + 256 * LD, LD ? 4 : 2) wgrad_dma_kernel(c
 
         // ---- A pieces (dY): piece k of this wave = tile rows (wave + 4k) * RPA + lane / CPA ----------------------------
         unsigned a_off[NPA];
-    #pragma unroll
+#pragma unroll
         for (int k = 0; k < NPA; ++k) {
             const int row = (wave + 4 * k) * RPA + lane / CPA;
             const int lchunk = (lane % CPA) ^ (wg_key<RBA>(row) << 1);
@@ -377,7 +387,7 @@ __global__ void __launch_bounds__(256 + 256 * LD, LD ? 4 : 2) wgrad_dma_kernel(c
         unsigned b_ci[NPB];
         bool b_cok[NPB];
         const int ohw = p.OH * p.OW;
-    #pragma unroll
+#pragma unroll
         for (int k = 0; k < NPB; ++k) {
             const int row = (wave + 4 * k) * RPB + lane / CPB;
             const int lchunk = (lane % CPB) ^ (wg_key<RBB>(row) << 1);
@@ -398,13 +408,13 @@ __global__ void __launch_bounds__(256 + 256 * LD, LD ? 4 : 2) wgrad_dma_kernel(c
         auto load_tile = [&](int kt, int stage) {
             unsigned char* as_w = smem + stage * STAGE + wave_u * 1024;
             unsigned char* bs_w = smem + stage * STAGE + BKP * RBA + wave_u * 1024;
-    #pragma unroll
+#pragma unroll
             for (int k = 0; k < NPA; ++k) {
                 const unsigned v = a_off[k];
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(as_w + k * 4096), 16, v, 0, 0, 0);
                 a_off[k] = v == 0xFFFFFFFFu ? v : v + a_step;
             }
-    #pragma unroll
+#pragma unroll
             for (int k = 0; k < NPB; ++k) {
                 const int m = pix_begin + kt * BKP + (wave + 4 * k) * RPB + lane / CPB;
                 const int xh = boh[k] * p.stride + b_dh[k], xw = bow[k] * p.stride + b_dw[k];
@@ -425,24 +435,59 @@ __global__ void __launch_bounds__(256 + 256 * LD, LD ? 4 : 2) wgrad_dma_kernel(c
         };
 
 
-        if (nkt > 0) load_tile(0, 0);
-        __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nkt) load_tile(kt + 1, cur ^ 1);
-            if constexpr (!LD) mma_tile(cur);
+        if constexpr (NST > 2) {
+            // tile kt lives in stage kt % NST.  At the barrier that opens step kt the loaders have retired tile kt (in-order
+            // return: vmcnt <= the pieces of the NST - 2 newer tiles still flying) and the compute waves are done with tile
+            // kt - 1, whose stage takes tile kt + NST - 1 while they multiply tile kt.
+            constexpr int NPL = NPA + NPB;
+#pragma unroll
+            for (int t = 0; t < NST - 1; ++t)
+                if (t < nkt) load_tile(t, t);
+            int fill = NST - 1;                 // stage of the next tile to issue
+            for (int kt = 0; kt < nkt; ++kt) {
+                if (NST == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPL) : "memory");
+                else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + NST - 1 < nkt) load_tile(kt + NST - 1, fill);
+                fill = fill == NST - 1 ? 0 : fill + 1;
+            }
+            __builtin_amdgcn_s_barrier();     // closes the ring: matches the compute waves' barrier before their epilogue
+            return;
+        } else {
+            if (nkt > 0) load_tile(0, 0);
             __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < nkt) load_tile(kt + 1, cur ^ 1);
+                if constexpr (!LD) mma_tile(cur);
+                __syncthreads();
+            }
+            if constexpr (LD) return;     // (the epilogue below has no block-wide barrier)
         }
-        if constexpr (LD) return;     // (the epilogue below has no block-wide barrier)
     } else {
-        __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            mma_tile(kt & 1);
+        if constexpr (NST > 2) {
+            int cs = 0;
+            for (int kt = 0; kt < nkt; ++kt) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                mma_tile(cs);
+                cs = cs == NST - 1 ? 0 : cs + 1;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // every wave is done reading the ring: the epilogue reuses it
+            asm volatile("" ::: "memory");
+        } else {
             __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                mma_tile(kt & 1);
+                __syncthreads();
+            }
         }
     }
 
-    if constexpr (BCO == 128 && BCI == 128) {
+    if constexpr (NCW == 8 || (BCO == 128 && BCI == 128)) {
         // The slab tile leaves through LDS (the ring is free now): each wave transposes its 64 x 64 accumulator block into
         // [row][col] fp32 rows (stride 68 words: the four row groups of a fragment land on disjoint banks) and stores 16 bytes
         // per lane, 256 contiguous bytes per row -- 16 store instructions per lane instead of 64 four-byte ones in 64-byte
@@ -450,7 +495,7 @@ __global__ void __launch_bounds__(256 + 256 * LD, LD ? 4 : 2) wgrad_dma_kernel(c
         if (!p.atomic) {
             constexpr int RS = 68;
             float* wt = reinterpret_cast<float*>(smem) + wave * (32 * RS);
-            static_assert(4 * 32 * RS * 4 <= 2 * STAGE, "the four wave tiles (32 rows at a time) fit in the ring");
+            static_assert(NCW * 32 * RS * 4 <= NST * STAGE, "the waves' tiles (32 rows at a time) fit in the ring");
             float* slab = p.part + (size_t)sp * p.CoRows * p.Ncols;
             const int c4 = (lane & 15) * 4, r0 = lane >> 4;
             const int col = col0 + wj * 64 + c4;
@@ -478,22 +523,22 @@ __global__ void __launch_bounds__(256 + 256 * LD, LD ? 4 : 2) wgrad_dma_kernel(c
             return;
         }
     }
-    wgrad_store<TI, TJ, BCO, BCI>(p, acc, sp, co0, col0, wi, wj, q16, g);
+    if constexpr (NCW == 4) wgrad_store<TI, TJ, BCO, BCI>(p, acc, sp, co0, col0, wi, wj, q16, g);     // (8 waves: slab stores only)
 }
 
-template <typename T, int BCO, int BCI, int LD = 0>
+template <typename T, int BCO, int BCI, int LD = 0, int BKP = 64, int NST = 2, int NCW = 4>
 int launch_dma(const WgradParams& p, int split, hipStream_t s) {
-    constexpr int smem = 2 * 64 * (BCO * 2 + BCI * 2);
+    constexpr int smem = NST * BKP * (BCO * 2 + BCI * 2);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, BCO, BCI, LD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, BCO, BCI, LD, BKP, NST, NCW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     WgradParams q = p;
     q.ncol_tiles = (p.Ncols + BCI - 1) / BCI;
     q.nco_tiles = (p.CoRows + BCO - 1) / BCO;
-    hipLaunchKernelGGL((wgrad_dma_kernel<T, BCO, BCI, LD>), dim3(q.ncol_tiles * q.nco_tiles * split), dim3(256 + 256 * LD), smem, s, q);
+    hipLaunchKernelGGL((wgrad_dma_kernel<T, BCO, BCI, LD, BKP, NST, NCW>), dim3(q.ncol_tiles * q.nco_tiles * split), dim3(64 * NCW + 256 * LD), smem, s, q);
     CY_LAUNCH_CHECK();
     return 0;
 }
@@ -524,10 +569,19 @@ int dispatch_dma(const WgradParams& p, int split, int cap, hipStream_t s) {
     // the slab traffic) for the same number of blocks; the engine times both (layers with a small weight matrix and many pixels)
     int bco = tile_of(p.CoRows), bci = tile_of(p.Ncols);
     if (cap == 64) { if (bco > 64) bco = 64; if (bci > 64) bci = 64; }
-    // CY_WGRAD_LOADERS: 0 = four self-staging waves everywhere, 1 = loader waves for the 128 x 128 tile only, 2 (default) = for every
-    // tile with at least 64 channels on both sides (measured on one box: 821 -> 830 -> 832 images/s for 0 / 1 / 2)
+    // CY_WGRAD_LOADERS: 0 = four self-staging waves everywhere, 1 = loader waves for the 128 x 128 tile only, 2 = for every tile with
+    // at least 64 channels on both sides, 4 (default) = 2 + the 256 x 128 tile on eight compute waves for layers with >= 256 output
+    // channels, 5 = 4 + the 128 x 256 tile for the 128-channel layers, 3 = 2 with the 128 x 128 tile on a four-stage ring.
+    // Measured, each level with its own tuned split table, same-box pairs: 0 -> 1 -> 2: 821 -> 830 -> 832 images/s; 2 -> 4: 850.5 ->
+    // 863.8; 3 is 0.3 % behind 2; 5 is 0.85 % behind 4 although its kernels alone are faster (128 -> 128 3x3 @76x76: 47 -> 41 us): the
+    // weight gradients run beside the trunk's dgrad / BN kernels, and one-block-per-CU tiles at the 76 x 76 stage get in their way.
     static int loaders = -1;
-    if (loaders < 0) { const char* e = getenv("CY_WGRAD_LOADERS"); loaders = e ? atoi(e) : 2; }
+    if (loaders < 0) { const char* e = getenv("CY_WGRAD_LOADERS"); loaders = e ? atoi(e) : 4; }
+    if (loaders >= 4 && cap != 64 && !p.atomic) {
+        if (p.CoRows >= 256 && bci == 128) return launch_dma<T, 256, 128, 1, 64, 3, 8>(p, split, s);
+        if (loaders == 5 && bco == 128 && p.Ncols >= 256) return launch_dma<T, 128, 256, 1, 64, 3, 8>(p, split, s);
+    }
+    if (loaders == 3 && bco == 128 && bci == 128) return launch_dma<T, 128, 128, 1, 32, 4>(p, split, s);     // experiment: counted-vmcnt ring
     if (loaders && bco == 128 && bci == 128) return launch_dma<T, 128, 128, 1>(p, split, s);
     if (loaders >= 2) {
         if (bco == 128 && bci == 64) return launch_dma<T, 128, 64, 1>(p, split, s);

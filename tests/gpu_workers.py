@@ -107,6 +107,29 @@ def rccl(out):
         json.dump(doc, f)
 
 
+def wgrad_case(out, dt, N, Ci, H, Co, ks, st, split):
+    """One cy_conv_wgrad + fold of tests/test_gpu_r3.py::test_wgrad_eight_wave_tile_matches_torch in this process (whose
+    environment decides which kernel variant the library takes): the folded gradient as a list."""
+    import torch
+    import complex_yolov4_pytorch_amd.ops as ops
+    from complex_yolov4_pytorch_amd.ops import View
+    N, Ci, H, Co, ks, st, split = [int(v) for v in (N, Ci, H, Co, ks, st, split)]
+    code = ops.dtype_code(dt)
+    pad = (ks - 1) // 2
+    rnd = (lambda t: t.bfloat16().float()) if dt == 'bf16' else (lambda t: t.half().float())
+    g = torch.Generator().manual_seed(5)
+    x = rnd(torch.randn(N, Ci, H, H, generator=g))
+    OH = (H + 2 * pad - ks) // st + 1
+    dy = rnd(torch.randn(N, Co, OH, OH, generator=g))
+    xv, dyv = View.from_nchw(x.to('cuda'), code), View.from_nchw(dy.to('cuda'), code)
+    part = torch.full((split, dyv.C, ks * ks * Ci), float('nan'), device='cuda')
+    ops.conv_wgrad(dyv, xv, ks, st, pad, part, split)
+    gw = torch.zeros(Co, Ci, ks, ks, device='cuda')
+    ops.wgrad_reduce(part, split, dyv.C, Ci, ks, Co, Ci, 1.0, False, gw)
+    with open(out, 'w') as f:
+        json.dump(dict(grad=gw.flatten().cpu().tolist()), f)
+
+
 if __name__ == '__main__':
     job, args = sys.argv[1], sys.argv[2:]
-    {'det_hash': det_hash, 'rccl': rccl}[job](*args)
+    {'det_hash': det_hash, 'rccl': rccl, 'wgrad_case': wgrad_case}[job](*args)

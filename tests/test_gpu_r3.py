@@ -59,10 +59,11 @@ def test_v4_16bit_band_at_benchmark_shape(golden, dtype):
     assert np.median(err) < b['ghead']
 
 
-def _worker(job, tmp_path, name, *args, timeout=600):
+def _worker(job, tmp_path, name, *args, timeout=600, env_extra=None):
     out = os.path.join(str(tmp_path), name + '.json')
     env = dict(os.environ)
     env.pop('CY_TUNE_RECORD', None)
+    env.update(env_extra or {})
     r = subprocess.run([sys.executable, '-m', 'tests.gpu_workers', job, out] + [str(a) for a in args], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -169,6 +170,37 @@ def test_wgrad_atomic_single_slab_matches_split_slabs(dt, case):
         assert float((gw - wref).abs().max()) <= tol, k
     for k in ((True, 5), (True, 23)):
         assert float((grads[k] - grads[(False, 5)]).abs().max()) <= 2e-5 * scale * math.sqrt(N * OH * OH / 64), k
+
+
+@pytest.mark.parametrize('dt', ['f16', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 96, 19, 320, 3, 1, 3), (1, 128, 38, 256, 3, 2, 2), (3, 256, 19, 512, 1, 1, 1), (2, 64, 24, 288, 3, 1, 4)])
+def test_wgrad_eight_wave_tile_matches_torch(tmp_path, dt, case):
+    """The 256 x 128 weight-gradient tile (eight compute + four loader waves, three-stage ring with counted vmcnt; taken for layers
+    with >= 256 output channels) against float64 torch: whole and partial channel tiles (320 = 256 + 64, 288), partial column tiles
+    (9 * 96 = 864), stride 2, 1x1, splits that cut the pixel range unevenly -- and against the 128 x 128 loader-wave kernel, which
+    must give the same slabs up to fp32 summation order."""
+    import complex_yolov4_pytorch_amd.ops as ops
+    from complex_yolov4_pytorch_amd.ops import View
+    code = ops.dtype_code(dt)
+    N, Ci, H, Co, ks, st, split = case
+    pad = (ks - 1) // 2
+    rnd = (lambda t: t.bfloat16().float()) if dt == 'bf16' else (lambda t: t.half().float())
+    g = torch.Generator().manual_seed(5)
+    x = rnd(torch.randn(N, Ci, H, H, generator=g))
+    OH = (H + 2 * pad - ks) // st + 1
+    dy = rnd(torch.randn(N, Co, OH, OH, generator=g))
+    wref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, ks, ks), dy.double(), st, pad).float()
+    xv, dyv = View.from_nchw(x.to(DEV), code), View.from_nchw(dy.to(DEV), code)
+    part = torch.full((split, dyv.C, ks * ks * Ci), float('nan'), device=DEV)
+    ops.conv_wgrad(dyv, xv, ks, st, pad, part, split)
+    gw = torch.zeros(Co, Ci, ks, ks, device=DEV)
+    ops.wgrad_reduce(part, split, dyv.C, Ci, ks, Co, Ci, 1.0, False, gw)
+    scale = float(wref.abs().max())
+    assert float((gw.cpu() - wref).abs().max()) <= (3e-2 if dt == 'bf16' else 4e-3) * scale
+    # the same call in a process where the library never takes the eight-wave tile (CY_WGRAD_LOADERS is read once per process)
+    out = _worker('wgrad_case', tmp_path, 'w', dt, *case, env_extra={'CY_WGRAD_LOADERS': '2'})
+    other = torch.tensor(out['grad']).reshape(Co, Ci, ks, ks)
+    assert float((gw.cpu() - other).abs().max()) <= 2e-5 * scale * (N * OH * OH / 64) ** 0.5
 
 
 # (dY channels = conv Cout, dX channels = conv Cin, dX height, dX width, batch): the direct kernel's shape (64 -> 32) with whole
