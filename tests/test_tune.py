@@ -21,9 +21,7 @@ def _restore_tune_module():
     """Every test reloads tune.py under its own environment; leave the module as a fresh default import for whoever runs next."""
     yield
     import complex_yolov4_pytorch_amd.tune as tune
-    for k in ('CY_TUNE_CACHE', 'CY_TUNE_CACHE_PATH', 'CY_TUNE_RECORD'):
-        os.environ.pop(k, None)
-    importlib.reload(tune)
+    importlib.reload(tune)          # (monkeypatch has restored the caller's environment by now)
 
 
 def _fresh_tune(monkeypatch, **env):
