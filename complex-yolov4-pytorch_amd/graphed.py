@@ -29,7 +29,12 @@ from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, warmup=3, max_graphs=32):
+    """``warmup``: how many batches of a new (image shape, target rows) run EAGERLY before that shape is captured (default 1).
+    They are ordinary training steps on the batches the caller passes -- nothing is stepped twice -- and double as what a
+    capture needs to have happened once: kernel / tile choices, workspaces, optimizer state.  ``warmup=0`` captures at first
+    sight and is for callers that have already run an eager step of that shape themselves."""
+
+    def __init__(self, model, optimizer, warmup=1, max_graphs=32):
         self.model = getattr(model, 'module', model)
         if self.model is not model:
             raise ops.CyoloError('GraphedTrainStep captures a single-process step (no gradient all-reduce inside the graph)')
@@ -40,6 +45,7 @@ class GraphedTrainStep:
             raise ops.CyoloError('GraphedTrainStep needs the two-stream backward (CY_WGRAD_SIDE_STREAM=0 is set): see the module docstring')
         self.opt, self.warmup, self.max_graphs = optimizer, int(warmup), int(max_graphs)
         self._graphs = {}
+        self._seen = {}
         self.replays = 0
 
     def _eager(self, x, tg):
@@ -52,13 +58,6 @@ class GraphedTrainStep:
     def _capture(self, x, tg):
         ops.check_device_tensor(x, 'GraphedTrainStep')
         sx, st = x.clone(), tg.clone()
-        # warm-up on a side stream (torch's capture protocol): kernel / tile tuning, workspaces, optimizer state
-        s = torch.cuda.Stream(device=x.device)
-        s.wait_stream(torch.cuda.current_stream(x.device))
-        with torch.cuda.stream(s):
-            for _ in range(self.warmup):
-                self._eager(sx, st)
-        torch.cuda.current_stream(x.device).wait_stream(s)
         torch.cuda.synchronize(x.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -70,8 +69,10 @@ class GraphedTrainStep:
         key = (tuple(x.shape), int(targets.shape[0]), self.model.training)
         rec = self._graphs.get(key)
         if rec is None:
-            if len(self._graphs) >= self.max_graphs:
-                return self._eager(x, targets)        # too many shapes: this one runs eagerly
+            seen = self._seen.get(key, 0)
+            if seen < self.warmup or len(self._graphs) >= self.max_graphs:
+                self._seen[key] = seen + 1
+                return self._eager(x, targets)        # a real step of this batch (new shape, or too many shapes already)
             rec = self._graphs[key] = self._capture(x.float().contiguous(), targets)
             # (the capture itself does not execute the step: fall through to the replay for this batch)
         rec['x'].copy_(x, non_blocking=True)

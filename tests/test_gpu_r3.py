@@ -306,11 +306,13 @@ def test_direct1x1_dgrad_bn_sums_and_prefetched_fan_in(dt, accum, case):
         assert torch.equal(g3.buf, g2.buf)
 
 
-def test_graphed_train_step_equals_eager_steps():
+@pytest.mark.parametrize('warmup', [0, 1])
+def test_graphed_train_step_equals_eager_steps(warmup):
     """graphed.GraphedTrainStep (forward + loss + backward + Adam as ONE captured hipGraph, replayed) against the same steps
     issued eagerly, deterministic mode: parameters, BatchNorm running statistics and losses after three different batches are
     bit-identical; a learning-rate change between replays is honoured without re-capture; a new target count captures a
-    second graph."""
+    second graph (warmup=0) or runs its first batch eagerly (warmup=1, the default: warm-up batches are ordinary steps, no
+    batch is ever stepped twice)."""
     import copy
     from complex_yolov4_pytorch_amd.graphed import GraphedTrainStep
     from complex_yolov4_pytorch_amd.optim import FusedAdam
@@ -329,7 +331,7 @@ def test_graphed_train_step_equals_eager_steps():
             opt.step()
             return loss
         eager(*batches[0])                                        # both arms: one eager step first (tuning, state, workspaces)
-        step = GraphedTrainStep(model, opt, warmup=0) if graphed else eager
+        step = GraphedTrainStep(model, opt, warmup=warmup) if graphed else eager
         losses = []
         for i, (x, tg) in enumerate(batches + [extra]):
             if i == 2:
@@ -338,7 +340,7 @@ def test_graphed_train_step_equals_eager_steps():
             losses.append(float(step(x, tg).detach()))
         torch.cuda.synchronize()
         if graphed:
-            assert step.replays == 4 and len(step._graphs) == 2
+            assert (step.replays, len(step._graphs)) == ((4, 2) if warmup == 0 else (2, 1))
         runs.append((losses, copy.deepcopy({k: v.detach().clone() for k, v in model.state_dict().items()})))
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     for k, v in runs[0][1].items():
