@@ -17,7 +17,6 @@ Differences from the reference that a caller can observe (all deliberate, SURVEY
     (bf16 needs no loss scaling); ``dtype='f32'`` is the parity mode;
   * ``deterministic=True`` replaces the fp32-atomic reductions by fixed-order ones: repeats are bit-identical.
 """
-import math
 
 import torch
 import torch.nn as nn

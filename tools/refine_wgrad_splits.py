@@ -16,7 +16,6 @@ single-stream step fell 4.02 -> 3.71 ms -- and the benchmarked two-stream step g
 alternations).  The refined splits are mostly deeper (more, shorter blocks): alone that fills the chip better, beside the trunk's
 dgrad / BN kernels it takes CUs from the critical path.  The shipped table therefore stays the engine's own; this tool is kept
 as the measurement."""
-import json
 import os
 import sys
 
