@@ -2,7 +2,10 @@
 """Headline benchmark (BASELINE.json): BEV images/s of a 608x608 Complex-YOLOv4 TRAIN step.
 
   python bench.py --gpus N --steps K --warmup W [--config train608|infer32|train1024] [--dtype f16|bf16|f32]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  N > 1: either under the launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+  --master-port P bench.py --gpus N ...; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or plainly as
+  `python bench.py --gpus N`: without WORLD_SIZE in the environment the script starts its own N ranks (one process per GPU,
+  the reference's mp.spawn in src/train.py:46-52) and rank 0 prints the line.
 
 train608 (default, BASELINE configs[1]): one step = forward + GIoU loss + backward + Adam update of complex_yolov4.cfg on a
 fixed synthetic batch of 16 BEV images per GPU; inputs are resident in HBM before the timed region.  Weak scaling: every
@@ -187,9 +190,37 @@ def measure_inference(dev, batch, size, dtype, steps, warmup):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    gflop = sum(e._conv_work(rec)[0] for e in model._engines.values() for rec in e.plan.convs) / 1e9
+    # the reference's own contract (evaluate.py:32-45): model(x) hands its outputs to the HOST (darknet2pytorch.py:228), and
+    # post_processing_v2 starts from a host tensor (here: H2D + select + merge-NMS on the device + detections back to the host)
+    from complex_yolov4_pytorch_amd.utils.evaluation_utils import post_processing_v2
+    model.cpu_outputs = True
+    pred_host = pred.cpu()
+
+    def ref_step():
+        with torch.no_grad():
+            out = model(x)
+            post_processing_v2(pred_host, 0.5, 0.5)
+        return out
+
+    for _ in range(max(1, warmup // 2)):
+        ref_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nref = max(2, steps // 2)
+    for _ in range(nref):
+        ref_step()
+    torch.cuda.synchronize()
+    dt_ref = (time.perf_counter() - t0) / nref
     model.release_engines()
     return dict(metric='BEV images/s (%dx%d) inference + rotated NMS' % (size, size), value=round(batch / dt, 2), unit='images/s',
-                ms_per_step=round(1e3 * dt, 3), steps=steps, dtype=dtype,
+                ms_per_step=round(1e3 * dt, 3), steps=steps, dtype=dtype, step_gflop=round(gflop, 1),
+                step_tflops=round(gflop / dt / 1e3, 1), step_frac=round(gflop / dt / 1e3 / MFMA_PEAK_TFLOPS[dtype], 4),
+                reference_contract=dict(value=round(batch / dt_ref, 2), unit='images/s', ms_per_step=round(1e3 * dt_ref, 3), steps=nref,
+                                        workload='model(x) returns its [%d, %d, 10] fp32 outputs on the HOST (D2H, reference '
+                                                 'darknet2pytorch.py:228), post_processing_v2 takes a HOST tensor of synthetic '
+                                                 'predictions (H2D + device select / merge-NMS + detections to the host)'
+                                                 % (batch, pred.shape[1])),
                 workload='complex_yolov4.cfg model.eval() forward, batch %d, %dx%d (outputs stay on the device: no 29 MB D2H) + '
                          'post_processing_v2 on the device over SYNTHETIC predictions with 256 candidates/image (random-init weights '
                          'yield no confident boxes), both stages in every timed step' % (batch, size, size))
@@ -222,40 +253,6 @@ def batch_source(dev, batch, size, mosaic, seed=0):
     return make
 
 
-def measure_train(dev, batch, size, dtype, steps, warmup, mosaic=False):
-    """A train step configuration measured briefly on one GPU (the `other_configs` entries of the default run)."""
-    torch.manual_seed(0)
-    model = Darknet(CFG, use_giou_loss=True, dtype=dtype).to(dev)
-    model.train()
-    opt = create_optimizer(_OptCfg, model)
-    source = batch_source(dev, batch, size, mosaic)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        x, tg = source()
-        loss, _ = model(x, tg)
-        loss.backward()
-        opt.step()
-        return loss
-
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    final = float(loss.detach().reshape(-1)[0])
-    model.release_engines()
-    del opt, model
-    torch.cuda.empty_cache()
-    return dict(metric='BEV images/s (%dx%d) train step' % (size, size), value=round(batch / dt, 2), unit='images/s',
-                ms_per_step=round(1e3 * dt, 3), steps=steps, dtype=dtype, loss_final=round(final, 4),
-                workload='complex_yolov4.cfg train step (%sfwd + rotated-GIoU loss + bwd + Adam), batch %d, %dx%d'
-                         % ('device mosaic of four %dx%d maps per sample + ' % (size // 2, size // 2) if mosaic else '', batch, size, size))
-
-
 def measure_other(config, dtype, steps, warmup):
     """One of the other configurations, measured by this same script in a fresh process (its ONE JSON line, reduced)."""
     import subprocess
@@ -264,10 +261,96 @@ def measure_other(config, dtype, steps, warmup):
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
         d = json.loads(r.stdout.strip().splitlines()[-1])
-        return dict(metric=d['metric'], value=d['value'], unit=d['unit'], ms_per_step=d['ms_per_step'], steps=d['steps'], dtype=d['dtype'],
-                    workload=d['config']['workload'], loss_final=d['config'].get('loss_final'), process='fresh')
+        out = dict(metric=d['metric'], value=d['value'], unit=d['unit'], ms_per_step=d['ms_per_step'], steps=d['steps'], dtype=d['dtype'],
+                   workload=d['config']['workload'], loss_final=d['config'].get('loss_final'), process='fresh')
+        # roofline of the configuration: its whole-step algorithmic FLOPs over its wall clock against the dense MFMA peak
+        out.update({k: d['step'][k] for k in ('step_gflop', 'step_tflops', 'step_frac') if d.get('step') and k in d['step']})
+        if d.get('reference_contract'):
+            out['reference_contract'] = d['reference_contract']
+        return out
     except Exception as e:      # noqa: BLE001 -- the headline line must still be printed
         return dict(error='%s: %r' % (config, e))
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv, sim=False):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU (what the reference's
+    mp.spawn does, src/train.py:46-52), through torch.distributed.run on 127.0.0.1; rank 0's JSON line is the children's
+    stdout, passed through.  -> exit status."""
+    import subprocess
+    if not sim:
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write('bench.py: --gpus %d needs %d GPUs on this node, %d visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)\n'
+                             % (n, n, have))
+            return 2
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cores(256) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def sim_main(a, rank, world):
+    """tests/test_bench_launch.py: the rank plumbing of this script (launch, barrier, max-over-ranks timing, per-rank line) on CPU
+    ranks over gloo, operator layer = tests/opsim.py, mini cfg.  Nothing here is a measurement."""
+    from tests import opsim
+    from tests.util import mini_cfg_path
+
+    class _MP:
+        def setattr(self, o, n, v):
+            setattr(o, n, v)
+    opsim.install(_MP())
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29512')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    torch.set_num_threads(2)
+    model = Darknet(mini_cfg_path(), use_giou_loss=True, dtype='f32')
+    model.train()
+    net = RcclDataParallel(model, bucket_bytes=64 << 10)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x, tg = syn.bev_images(2, 64, seed=rank, sparsity=0.5), syn.targets(2, 3, 64, seed=rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = net(x, tg)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    every = [torch.zeros_like(elapsed) for _ in range(world)]
+    dist.all_gather(every, elapsed)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    w0 = next(model.parameters()).detach().double().sum().reshape(1)
+    ws = [torch.zeros_like(w0) for _ in range(world)]
+    dist.all_gather(ws, w0)
+    dist.destroy_process_group()
+    if rank == 0:
+        emit({'metric': 'SIMULATED ranks (CPU, gloo, mini cfg): launch plumbing only', 'value': round(world * 2 * a.steps / float(elapsed), 3),
+              'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * float(elapsed) / a.steps, 3),
+              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+              'config': {'workload': 'simulated', 'global_batch': 2 * world, 'parallelism': 'dp%d' % world,
+                         'loss_final': round(float(loss.detach().reshape(-1)[0]), 4)},
+              'per_rank_ms_per_step': [round(1e3 * float(t) / a.steps, 3) for t in every],
+              'params_equal_across_ranks': bool(all(float(w) == float(ws[0]) for w in ws))})
 
 
 def main():
@@ -286,16 +369,23 @@ def main():
     ap.add_argument('--graph', type=int, default=0, help='1: the step as one captured hipGraph (graphed.GraphedTrainStep); default 0 = '
                     'eager launches: on ROCm 7.2 the replay of the 660-node, two-stream graph takes 33.1 ms against 19.2 ms eager '
                     '(DESIGN.md section 5), so the measured configuration is the eager one')
+    ap.add_argument('--sim', action='store_true', help=argparse.SUPPRESS)     # tests only: CPU ranks over gloo on tests/opsim.py
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     a.batch = a.batch or cfg['batch']
     a.size = a.size or cfg['size']
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a.gpus, sys.argv[1:], sim=a.sim))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if a.gpus > 1 and world != a.gpus:
-        sys.exit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world))
+    if a.gpus != world and (a.gpus > 1 or world > 1):
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks (use --nproc-per-node %d)' % (a.gpus, world, a.gpus))
+    if a.sim:
+        return sim_main(a, rank, world)
+    if torch.cuda.device_count() <= local:
+        sys.exit('bench.py: rank %d needs GPU %d but this node exposes %d device(s)' % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     force_ddp = os.environ.get('CY_DDP_FORCE') == '1'
@@ -304,6 +394,7 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs on this driver
         dist.init_process_group('nccl', device_id=dev)
 
     if cfg['kind'] == 'infer':
@@ -319,7 +410,9 @@ def main():
                     'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
                     'data': 'synthetic', 'config': {'workload': r['workload'], 'global_batch': world * a.batch,
                                                     'parallelism': 'replicas%d' % world},
-                    'roofline': None, 'cpu_baseline': None}
+                    'roofline': None, 'cpu_baseline': None,
+                    'step': {k: r[k] for k in ('step_gflop', 'step_tflops', 'step_frac')},
+                    'reference_contract': r['reference_contract']}
         if dist.is_initialized():
             dist.destroy_process_group()
         if rank == 0:
@@ -367,14 +460,30 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if isinstance(net, RcclDataParallel):
+        net.exposed_events = []      # (before, after) the compute stream's wait for the all-reduce stream, one pair per step
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     sync()
-    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    mine = time.perf_counter() - t0
+    elapsed = torch.tensor([mine], device=dev, dtype=torch.float64)
+    per_rank_ms, exposed_ms = None, None
+    if isinstance(net, RcclDataParallel):
+        # how long the compute stream stood still at the end of backward waiting for the gradient all-reduce (the part of
+        # the collective that backward did NOT hide), averaged over the timed steps; max over ranks below
+        ex = [e0.elapsed_time(e1) for e0, e1 in (net.exposed_events or [])]
+        net.exposed_events = None
+        exposed = torch.tensor([sum(ex) / max(1, len(ex))], device=dev, dtype=torch.float64)
     if world > 1:
+        every = [torch.zeros_like(elapsed) for _ in range(world)]
+        dist.all_gather(every, elapsed)
+        per_rank_ms = [round(1e3 * float(t) / a.steps, 3) for t in every]
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(exposed, op=dist.ReduceOp.MAX)
+    if isinstance(net, RcclDataParallel):
+        exposed_ms = round(float(exposed), 3)
     elapsed = float(elapsed)
     final_loss = float(loss.detach().reshape(-1)[0])
 
@@ -462,6 +571,7 @@ def main():
         dist.barrier()
 
     fused_layers = max((len(e._sums_fused) for e in model._engines.values()), default=0)
+    sf_all = step_flops(model)         # per-GPU algorithmic FLOPs of one step (weak scaling: the same on every rank)
     if rank == 0:
         cpu = None
         others = None
@@ -492,9 +602,17 @@ def main():
                                    % ('device mosaic of four maps per sample + ' if cfg.get('mosaic') else '', a.batch, a.size, a.size, 24 if cfg.get('mosaic') else 6),
                        'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4),
                        'deterministic': bool(a.deterministic), 'issue': graph_note,
-                       'dgrad_bn_sums_layers': fused_layers},
+                       'dgrad_bn_sums_layers': fused_layers,
+                       'yolo_outputs': 'stay on the device in training (the reference copies 14.6 MB to the host every step, '
+                                       'darknet2pytorch.py:228, and train.py discards them)'},
             'roofline': roofline, 'cpu_baseline': cpu,
+            'step': dict(step_gflop=round(sf_all / 1e9, 1), step_tflops=round(sf_all / (elapsed / a.steps) / 1e12, 1),
+                         step_frac=round(sf_all / (elapsed / a.steps) / (MFMA_PEAK_TFLOPS[a.dtype] * 1e12), 4)),
         }
+        if per_rank_ms is not None:
+            line['per_rank_ms_per_step'] = per_rank_ms
+        if exposed_ms is not None:
+            line['allreduce_exposed_ms_per_step'] = exposed_ms      # 0 = fully hidden behind backward
         if others:
             line['other_configs'] = others
     if dist.is_initialized():

@@ -52,6 +52,9 @@ class RcclDataParallel(torch.nn.Module):
         self._pending = []
         self._sync = True
         self._form = EMPTY
+        # bench.py: a list here collects one (before, after) event pair per backward around the compute stream's wait for
+        # the all-reduce stream -- their distance is the part of the collective that backward did not hide
+        self.exposed_events = None
         module._pre_backward_hooks.append(self._pre_backward)
         module._post_backward_hooks.append(self._finish)
         module._module_grad_hooks.append(self._module_done)
@@ -136,7 +139,15 @@ class RcclDataParallel(torch.nn.Module):
         self._form = REDUCED if self._sync else LOCAL
         flat = model.flat_grad
         if flat is not None and flat.is_cuda and self._side is not None:
-            torch.cuda.current_stream(flat.device).wait_stream(self._side)
+            cur = torch.cuda.current_stream(flat.device)
+            if self.exposed_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self._side)
+                e1.record(cur)
+                self.exposed_events.append((e0, e1))
+            else:
+                cur.wait_stream(self._side)
 
 
 def reduce_tensor(tensor, world_size):
