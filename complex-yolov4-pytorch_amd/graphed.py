@@ -21,7 +21,8 @@ and the constructor refuses that configuration.
 A new (image shape, number of target rows) captures a new graph (KITTI batches differ in their number of boxes; pad the
 target rows to a few bucket sizes with rows of sample index -1 to bound the number of graphs -- such rows are rejected by
 cy_yolo_loss and only count as `errors` in the metrics).  Not for data-parallel runs yet: the gradient all-reduce hooks are
-not part of the capture.
+not part of the capture.  Not with optim.DynamicLossScale either (refused): the overflow scan sits between backward() and
+step() outside the capture; fp16 runs through this class use a static ``loss_scale``.
 """
 import torch
 
@@ -43,6 +44,11 @@ class GraphedTrainStep:
         import os
         if os.environ.get('CY_WGRAD_SIDE_STREAM', '1') == '0':
             raise ops.CyoloError('GraphedTrainStep needs the two-stream backward (CY_WGRAD_SIDE_STREAM=0 is set): see the module docstring')
+        if getattr(optimizer, 'skip_flag', None) is not None:
+            # a DynamicLossScale is attached: its cy_grad_nonfinite scan runs between backward() and step(), outside what this
+            # class captures, so replays would consult a flag nobody refreshes -- fp16 overflow protection would be silently off
+            raise ops.CyoloError('GraphedTrainStep does not capture optim.DynamicLossScale (the non-finite scan is not part of the '
+                                 'graph): use bf16, a static loss_scale, or the eager step')
         self.opt, self.warmup, self.max_graphs = optimizer, int(warmup), int(max_graphs)
         self._graphs = {}
         self._seen = {}
@@ -65,6 +71,9 @@ class GraphedTrainStep:
         return dict(graph=g, x=sx, tg=st, loss=loss)
 
     def __call__(self, x, targets):
+        if getattr(self.opt, 'skip_flag', None) is not None:
+            raise ops.CyoloError('a DynamicLossScale was attached to the optimizer after GraphedTrainStep was built: its overflow '
+                                 'check is not part of the captured step')
         targets = targets.to(x.device).float().contiguous()
         key = (tuple(x.shape), int(targets.shape[0]), self.model.training)
         rec = self._graphs.get(key)

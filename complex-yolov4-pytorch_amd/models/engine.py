@@ -119,6 +119,9 @@ class Engine:
         self._multi_heads = (hasattr(ops, 'yolo_loss_multi') and same and 1 <= len(plan.heads) <= 3
                              and os.environ.get('CY_HEADS_MULTI', '1') != '0' and getattr(device, 'type', str(device)) == 'cuda')
         self._pending_heads, self._head_table = [], None
+        # superseded head workspaces are kept for the engine's lifetime: a hipGraph captured while one of them was current
+        # (graphed.GraphedTrainStep) has its pointer baked into its kernel arguments and keeps writing there on every replay
+        self._retired_ws = []
         self._wgrad_ev, self._main_stream, self._side_scope = {}, None, None
         self.fwd_serial = 0
         self._reduce_groups = None
@@ -174,6 +177,7 @@ class Engine:
     def forward(self, x, targets, params, use_giou, img_size, weights_epoch=None):
         plan = self.plan
         self.fwd_serial += 1
+        self._pending_heads = []          # (a forward that raised after queueing a head must not leak it into this one)
         if self.stats_pair is not None and self.training:
             # the alternating statistics tables restart from a defined state every pass (complex_yolov4.cfg has an ODD number of
             # BatchNorm layers: the parity used to carry over from step to step, which a captured and replayed step cannot do)
@@ -387,6 +391,8 @@ class Engine:
         nT = targets.shape[0]
         need = ops.yolo_loss_workspace(self.N, rec['G'], rec['A'], rec['C'], nT)
         if self.loss_ws[h] is None or self.loss_ws[h].numel() < need:
+            if self.loss_ws[h] is not None:
+                self._retired_ws.append(self.loss_ws[h])
             self.loss_ws[h] = torch.empty(need, dtype=torch.uint8, device=self.device)
         dl = self.dlogits[h]
         if dl is None:
@@ -401,6 +407,8 @@ class Engine:
         if self._head_table is None or self._head_table[2] < nT:
             cap = max(nT, 64) if self._head_table is None else max(nT, 2 * self._head_table[2])     # room to grow: KITTI batches vary
             need = ops.yolo_loss_multi_workspace([r['G'] for r in recs], self.N, r0['A'], r0['C'], cap)
+            if self._head_table is not None:
+                self._retired_ws.append(self._head_table)      # (table and workspace: see __init__)
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             heads = []
             for r in recs:
@@ -488,7 +496,7 @@ class Engine:
             if key not in memo:
                 s0, cap = self.wsplit[idx], self.wsplit_cap[idx]
                 hit = tune.get(key)
-                if hit is not None and 1 <= abs(int(hit[0])) % 1000 <= max(cap, 512) and not (self.det and (int(hit[0]) < 0 or int(hit[0]) >= 1000)):
+                if hit is not None and self._wgrad_choice_ok(int(hit[0]), cap, dy.M):
                     memo[key] = int(hit[0])
                     tune.put(key, *hit)
                 elif self.det and not _DET_TIMING:
@@ -537,6 +545,20 @@ class Engine:
         if self.watomic:
             self.wpart.zero_()        # atomic slabs start from zero (the timing launches added into them); the folds keep them so
         self._reduce_groups = None
+
+    def _wgrad_choice_ok(self, v, cap, M):
+        """Is a persisted weight-gradient choice usable by THIS engine?  Encoding: s = plain split into s slabs, 1000 + s = the
+        same on 64 x 64 tiles, -s = atomic (s splits add into ONE slab).  The slab region of a layer holds ``cap`` slabs, so a
+        slab-writing mode needs s <= cap (a table from another cap formula or a CY_TUNE_CACHE_PATH file would otherwise write
+        into the next layer's slabs); an atomic split is bounded by the 512-pixel minimum per split; deterministic engines
+        take plain splits only."""
+        if v == 0:
+            return False
+        if v < 0:
+            return not self.det and 1 <= -v <= max(1, (M + 511) // 512)
+        if v >= 1000:
+            return not self.det and 1 <= v - 1000 <= cap
+        return 1 <= v <= cap
 
     # ---- conv kernel / tile choice ---------------------------------------------------------------------
     @property

@@ -59,8 +59,17 @@ class FusedAdam(torch.optim.Optimizer):
             self._grp_host[8 + i] = float(g['weight_decay'])
 
     def note_replayed(self):
-        """A captured step() was replayed by a graph (graphed.GraphedTrainStep): keep the host's step bookkeeping in line."""
+        """A captured step() was replayed by a graph (graphed.GraphedTrainStep): the device counter advanced by one, the
+        host's copies (``_steps`` and the per-parameter ``step`` entries a checkpoint carries) follow."""
         self._steps += 1
+        for st in self.state.values():
+            st['step'] = self._steps
+
+    def state_dict(self):
+        for st in self.state.values():          # (whatever path advanced _steps last: a checkpoint never carries a stale count)
+            if 'step' in st:
+                st['step'] = self._steps
+        return super().state_dict()
 
     def _build(self):
         items = []
@@ -85,18 +94,26 @@ class FusedAdam(torch.optim.Optimizer):
         self._build()
         if self._table is None:
             return loss
-        self._steps += 1
+        # while a hipGraph is being CAPTURED no kernel runs: the step that the capture records happens at each replay
+        # (note_replayed), so the host's step count must not move here
+        capturing = self.capturable and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self._steps += 1
         b1, b2 = self.param_groups[0]['betas']
         for g in self.param_groups:
             assert tuple(g['betas']) == (b1, b2) and g['eps'] == self.param_groups[0]['eps'], 'betas/eps must be shared'
-        for st in self.state.values():
-            st['step'] = self._steps
+        if not capturing:
+            for st in self.state.values():
+                st['step'] = self._steps
         assert len(self.param_groups) <= 8
         skip = getattr(self, 'skip_flag', None)
         lrs, wds = [g['lr'] for g in self.param_groups], [g['weight_decay'] for g in self.param_groups]
         if self.capturable:
             dev = self._table[0].device
             if self._counter is None:
+                if capturing:
+                    raise ops.CyoloError('FusedAdam(capturable=True): run one eager step() before capturing it (the device step '
+                                         'counter would be created, and reset at every replay, inside the graph)')
                 self._counter = torch.full((1,), self._steps - 1, dtype=torch.int32, device=dev)
                 self._grp_dev = torch.zeros(16, dtype=torch.float32, device=dev)
                 self._grp_host = torch.zeros(16, dtype=torch.float32).pin_memory()

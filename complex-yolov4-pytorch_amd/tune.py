@@ -26,6 +26,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CACHE_PATH = os.path.join(_HERE, 'tune_cache', 'gfx950.json')
 
+# bump when the MEANING of an entry changes without a kernel edit (engine.py's split caps, hint numbering, key layout):
+# folded into the hash the table is validated against, so an older table is ignored instead of misread
+TABLE_VERSION = 2
+
 _sha = None
 _table = None
 _recorded = {}
@@ -36,6 +40,7 @@ def sources_sha():
     global _sha
     if _sha is None:
         h = hashlib.sha256()
+        h.update(b'table-version %d\0' % TABLE_VERSION)
         for f in sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.h*'))):
             with open(f, 'rb') as fh:
                 h.update(os.path.basename(f).encode() + b'\0' + fh.read())

@@ -70,3 +70,35 @@ def test_warmup_batches_and_overflow_shapes_are_single_eager_steps(monkeypatch):
     assert model.calls == [((2, 3, 4, 4), 5), ((2, 3, 4, 4), 5), ((2, 3, 4, 4), 7), ((2, 3, 4, 4), 5), ((2, 3, 4, 4), 5)]
     torch.testing.assert_close(model.w.detach(), w0 - 5 * 0.1 * torch.ones(3))
     assert step._seen == {((2, 3, 4, 4), 5, True): 4, ((2, 3, 4, 4), 7, True): 1}
+
+
+def test_refuses_a_dynamic_loss_scale(monkeypatch):
+    """the overflow scan of optim.DynamicLossScale is not part of the captured step -- refuse instead of replaying
+    with a flag nobody refreshes (at construction, and when a scaler is attached afterwards)."""
+    monkeypatch.delenv('CY_WGRAD_SIDE_STREAM', raising=False)
+    model = _Model()
+    opt = _Opt(model.parameters(), lr=0.1)
+    opt.skip_flag = torch.zeros(1, dtype=torch.int32)
+    with pytest.raises(ops.CyoloError, match='DynamicLossScale'):
+        GraphedTrainStep(model, opt)
+    opt.skip_flag = None
+    step = GraphedTrainStep(model, opt, warmup=5)
+    step(torch.ones(2, 3, 4, 4), torch.zeros(3, 8))
+    opt.skip_flag = torch.zeros(1, dtype=torch.int32)
+    with pytest.raises(ops.CyoloError, match='DynamicLossScale'):
+        step(torch.ones(2, 3, 4, 4), torch.zeros(3, 8))
+
+
+def test_wgrad_choice_validation_per_mode():
+    """a persisted weight-gradient split is only usable when its slabs fit the layer's slab region (plain and
+    64-tile: split <= cap), an atomic split is bounded by the 512-pixel minimum, deterministic engines take plain splits only."""
+    from complex_yolov4_pytorch_amd.models.engine import Engine
+    e = Engine.__new__(Engine)
+    e.det = False
+    cap, M = 12, 5776
+    assert e._wgrad_choice_ok(12, cap, M) and e._wgrad_choice_ok(1, cap, M)
+    assert not e._wgrad_choice_ok(13, cap, M) and not e._wgrad_choice_ok(512, cap, M) and not e._wgrad_choice_ok(0, cap, M)
+    assert e._wgrad_choice_ok(1012, cap, M) and not e._wgrad_choice_ok(1013, cap, M) and not e._wgrad_choice_ok(1000, cap, M)
+    assert e._wgrad_choice_ok(-12, cap, M) and not e._wgrad_choice_ok(-13, cap, M)         # ceil(5776 / 512) = 12
+    e.det = True
+    assert e._wgrad_choice_ok(12, cap, M) and not e._wgrad_choice_ok(1004, cap, M) and not e._wgrad_choice_ok(-4, cap, M)

@@ -114,6 +114,7 @@ def test_sources_sha_covers_every_kernel_source(monkeypatch, tmp_path):
     assert {'conv_pipe.hip', 'conv_igemm.hip', 'conv_wgrad.hip', 'conv_direct.hip', 'elementwise.hip', 'yolo_head.hip',
             'igemm_common.hpp', 'common.hpp', 'geometry.hpp'} <= names
     h = hashlib.sha256()
+    h.update(b'table-version %d\0' % tune.TABLE_VERSION)      # (the meaning of the entries: engine.py's caps / hint numbering)
     for f in files:
         with open(f, 'rb') as fh:
             h.update(os.path.basename(f).encode() + b'\0' + fh.read())
