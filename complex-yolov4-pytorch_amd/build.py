@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(HERE, '..', 'include')
 LIB = os.path.join(CSRC, 'libcyolo_hip.so')
-SOURCES = ['conv_igemm.hip', 'conv_pipe.hip', 'conv_direct.hip', 'conv_wgrad.hip', 'elementwise.hip', 'yolo_head.hip', 'riou_nms.hip', 'bev.hip', 'probe_dirty.hip']
+SOURCES = ['conv_igemm.hip', 'conv_pipe.hip', 'conv_direct.hip', 'conv_wgrad.hip', 'elementwise.hip', 'yolo_head.hip', 'riou_nms.hip', 'bev.hip']
 HEADERS = ['common.hpp', 'igemm_common.hpp', 'geometry.hpp', os.path.join(INCLUDE, 'cyolo_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC, '-Wno-unused-value']
 # Per-file flags.  yolo_head.hip / riou_nms.hip: the per-target / per-pair kernels index small polygon arrays dynamically; with the

@@ -719,19 +719,6 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const cy_reduce
     }
 }
 
-__global__ void probe_tr16_kernel(uint16_t* out) {
-    __shared__ __attribute__((aligned(16))) uint16_t tile[16 * 16];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 256; i += 64) tile[i] = (uint16_t)i;
-    __syncthreads();
-    const int q = lane & 15, g = lane >> 4;
-    const uint16_t* ptr = tile + (g * 4 + (q >> 2)) * 16 + ((q & 3) << 2);
-    const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(ptr));
-    typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
-    const u16x4 u = __builtin_bit_cast(u16x4, v);
-    for (int e = 0; e < 4; ++e) out[lane * 4 + e] = u[e];
-}
-
 }  // namespace
 
 extern "C" int cy_conv_wgrad_split(int M, int Co, int Ci, int ks) {
@@ -793,14 +780,6 @@ extern "C" int cy_wgrad_reduce_multi(const cy_reduce_desc* desc, const int32_t* 
     CY_ENTER();
     if (!desc || !blocks || nblocks < 1) return CY_ERR_ARG;   // (desc[i].lanes in {1, 2, 4, 8}: the table builder's contract)
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nblocks), dim3(256), 0, cy_s(s), desc, blocks, scale, accumulate);
-    CY_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int cy_probe_tr16(uint16_t* out, cy_stream_t s) {
-    CY_ENTER();
-    if (!out) return CY_ERR_ARG;
-    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, cy_s(s), out);
     CY_LAUNCH_CHECK();
     return 0;
 }

@@ -64,6 +64,23 @@ def lower_blocks(blocks):
     return mods
 
 
+def pool_geometry(n, k, s):
+    """-> (output extent, padding before) of a [maxpool] along one axis of extent n, as reference create_network picks its
+    module (darknet2pytorch.py:281-292): size odd / stride 1 -> nn.MaxPool2d(k, 1, k // 2); stride == size -> nn.MaxPool2d(k, k, 0);
+    anything else -> MaxPoolDark (:30-59): replicate padding of (k - 1) // 2 before and the same -- or one more, when the
+    darknet and torch output sizes differ -- after, then an unpadded pool.  A replicated border element is a copy of an element
+    the window already holds, so for a MAX it is the same as ignoring the taps beyond the border: value, winner and gradient
+    are those of the clipped window, which is what cy_maxpool_* computes for any (out, pad)."""
+    if s == 1 and k % 2:
+        return n, k // 2
+    if s == k:
+        return n // k, 0
+    p = k // 2
+    p1 = (k - 1) // 2
+    p2 = p1 + 1 if ((n - 1) // s) != ((n + 2 * p - k) // s) else p1
+    return (n + p1 + p2 - k) // s + 1, p1
+
+
 def trace_shapes(blocks, H, W):
     """[(type, (C, H, W)) per module] for an input of H x W."""
     mods = lower_blocks(blocks)
@@ -75,12 +92,7 @@ def trace_shapes(blocks, H, W):
             h = (h + 2 * m['pad'] - m['k']) // m['stride'] + 1
             w = (w + 2 * m['pad'] - m['k']) // m['stride'] + 1
         elif t == 'maxpool':
-            if m['stride'] == 1 and m['k'] % 2:
-                pass
-            elif m['stride'] == m['k']:
-                h, w = h // m['k'], w // m['k']
-            else:
-                raise ValueError('maxpool %d/%d is not used by the hot-path cfgs' % (m['k'], m['stride']))
+            h, w = pool_geometry(h, m['k'], m['stride'])[0], pool_geometry(w, m['k'], m['stride'])[0]
         elif t == 'upsample':
             h, w = h * m['stride'], w * m['stride']
         elif t == 'route':
@@ -246,7 +258,7 @@ class Plan:
             elif t == 'maxpool':
                 k, s = m['k'], m['stride']
                 rec = dict(op='pool', idx=i, x=src_prev, out=own_or_placed(i), k=k, stride=s,
-                           pad=k // 2 if s == 1 else 0)
+                           pad=pool_geometry(src_prev.st.H, k, s)[1])
                 out[i] = rec['out']
                 self.fwd.append(rec)
             elif t == 'upsample':

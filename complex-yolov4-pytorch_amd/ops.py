@@ -632,18 +632,6 @@ def pp2(pred, conf_thresh, nms_thresh):
     return outs, srcs
 
 
-def probe_dirty(pattern, blocks=2048, lds_bytes=64 * 1024):
-    """Test instrument: dirties VGPRs and LDS with ``pattern`` on every CU (cy_probe_dirty)."""
-    lib().call('cy_probe_dirty', int(pattern) & 0xFFFFFFFF, int(blocks), int(lds_bytes), None, _stream())
-
-
-def probe_tr16():
-    _require_gpu()
-    out = torch.zeros(64, 4, dtype=torch.int16, device='cuda')
-    lib().call('cy_probe_tr16', _p(out), _stream())
-    return out
-
-
 def bev_workspace(H, W, device='cuda'):
     """Zeroed workspace for bev_rasterize (the kernel leaves it zeroed, so it can be reused frame after frame)."""
     return torch.zeros(int(lib().raw('cy_bev_workspace')(H, W)), dtype=torch.uint8, device=device)

@@ -35,10 +35,6 @@ enum { CY_CONV_TILE_SHIFT = 8 };
 #define CY_CONV_TILE(h) ((h) << CY_CONV_TILE_SHIFT)
 
 int cy_version(void);
-/* Test instrument: a kernel of `blocks` x 256 threads that writes `pattern` into (almost) every VGPR of its waves and into
- * `lds_bytes` of LDS and exits -- run beside another kernel it exposes that kernel's reads of uninitialised registers / LDS
- * (tools/head_race_probe2.py).  No reference counterpart. */
-int cy_probe_dirty(uint32_t pattern, int blocks, int lds_bytes, uint32_t* sink, cy_stream_t s);
 /* Number of compute units / wavefront size of the current device (sanity for the loader). */
 int cy_device_info(int* cus, int* wave);
 
@@ -366,11 +362,6 @@ int cy_pp2_select(const float* pred, int B, int N, int C, float conf_thresh, voi
 int cy_pp2_merge(const float* pred, int B, int N, int C, const int32_t* cand_idx, const int32_t* cand_count,
                  int Kmax, float nms_thresh, void* workspace, float* det, int32_t* det_src, int32_t* det_count,
                  cy_stream_t s);
-
-/* Probe used by the test-suite to pin the gfx950 LDS transpose-read lane mapping the wgrad kernel
- * relies on: out[64][4] = what each lane receives from ds_read_b64_tr_b16 over a 16x16 u16 tile
- * holding its own linear index. */
-int cy_probe_tr16(uint16_t* out, cy_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * LiDAR -> bird's-eye-view rasteriser (reference removePoints + makeBVFeature,

@@ -4,6 +4,7 @@ Restates reference src/models/darknet2pytorch.py:
   create_network :235-401  (conv pad=(k-1)//2 if pad else 0; bias only without BN; module/param names
                             models.{i}.conv{n} / bn{n}; BN = torch defaults eps 1e-5 momentum 0.1)
   forward        :162-230  (route / grouped route / cat, shortcut add, maxpool, expand-upsample, yolo)
+  MaxPoolDark    :30-59    (replicate-padded pool for size / stride pairs nn.MaxPool2d is not used for)
   Mish           :22-28    (x * tanh(softplus(x)))
 as a functional graph walk over a {state-dict-name: tensor} dict, so gradients are available by name.
 The three/two YoloLayer heads use oracle/yolo_layer_ref.py.  This is also what bench.py times as
@@ -121,7 +122,13 @@ class DarknetRef:
                 elif s == k:
                     x = F.max_pool2d(x, k, s, 0)
                 else:
-                    raise ValueError('oracle: maxpool %d/%d not used by the hot-path cfgs' % (k, s))
+                    # MaxPoolDark (reference darknet2pytorch.py:30-59; complex_yolov3_tiny.cfg's size=2 stride=1 pool)
+                    p = k // 2
+                    pads = []
+                    for n in (x.shape[3], x.shape[2]):          # F.pad order: (left, right, top, bottom)
+                        p1 = (k - 1) // 2
+                        pads += [p1, p1 + 1 if ((n - 1) // s) != ((n + 2 * p - k) // s) else p1]
+                    x = F.max_pool2d(F.pad(x, pads, mode='replicate'), k, stride=s)
             elif t == 'upsample':
                 x = x.repeat_interleave(m['stride'], 2).repeat_interleave(m['stride'], 3)
             elif t == 'route':

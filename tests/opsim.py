@@ -248,11 +248,17 @@ def maxpool_argmax_bytes(N, H, OH, OW, C):
 def maxpool_fwd(x, y, k, stride, pad, argmax, scratch=None):
     a = _nchw(x)
     N, C, H, W = a.shape
-    yv, idx = F.max_pool2d(a, k, stride, pad, return_indices=True)
+    # the C ABI's contract: windows start at o * stride - pad and are clipped to the image; the output extent is the caller's
+    # (y.H, y.W) -- the trailing padding may differ from the leading one (MaxPoolDark, size 2 / stride 1)
+    ph, pw = max(0, (y.H - 1) * stride + k - H - pad), max(0, (y.W - 1) * stride + k - W - pad)
+    ap = F.pad(a, (pad, pw, pad, ph), value=float('-inf'))
+    yv, idx = F.max_pool2d(ap, k, stride, 0, return_indices=True)
+    yv, idx = yv[:, :, :y.H, :y.W], idx[:, :, :y.H, :y.W]
+    Wp = ap.shape[3]
     _store(y, yv)
     if argmax is not None:
         OH, OW = yv.shape[2], yv.shape[3]
-        ih, iw = idx // W, idx % W
+        ih, iw = idx // Wp - pad, idx % Wp - pad
         oh = torch.arange(OH).view(1, 1, OH, 1) * stride - pad
         ow = torch.arange(OW).view(1, 1, 1, OW) * stride - pad
         code = (ih - oh) * k + (iw - ow)

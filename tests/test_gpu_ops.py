@@ -38,7 +38,8 @@ def _rand(*shape, seed=0, scale=1.0):
 def test_tr16_lane_mapping():
     """gfx950 ds_read_b64_tr_b16: lane q of a 16-lane group receives column q of the 4x16 block whose rows
     are supplied by lanes (q>>2) -- the mapping conv_wgrad.hip relies on."""
-    got = ops.probe_tr16().cpu().numpy().astype(np.int64) & 0xffff
+    from tests import probes
+    got = probes.probe_tr16().cpu().numpy().astype(np.int64) & 0xffff
     exp = np.zeros((64, 4), dtype=np.int64)
     for lane in range(64):
         q, g = lane & 15, lane >> 4

@@ -7,6 +7,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 import complex_yolov4_pytorch_amd.ops as ops
+from tests import probes
 import complex_yolov4_pytorch_amd.synthetic as syn
 from complex_yolov4_pytorch_amd.ops import CY_F16, View
 
@@ -62,7 +63,7 @@ def busy_load():
             ops.conv_wgrad(y, x, 3, 1, 1, part, 8)
     elif load.startswith('dirty'):   # dirtyNaN / dirtyBig / dirtyZero: leave a pattern in every VGPR and LDS word of every CU
         pat = {'dirtyNaN': 0x7FC00001, 'dirtyBig': 0x4B800000, 'dirtyZero': 0, 'dirtyNeg': 0xBF800000, 'dirtyInt': 0x00000005}[load]
-        ops.probe_dirty(pat)
+        probes.probe_dirty(pat)
     elif load == 'bn':
         for _ in range(6):
             ops.bn_act_fwd(x, y, None, sc, sh, 2)
