@@ -5,7 +5,8 @@
 
 Runs one training step (forward + backward: that is where the engine times its candidates) of every configuration bench.py
 measures -- complex_yolov4.cfg 608x608 batch 16 in f16 and bf16, default and deterministic mode; 1024x1024 batch 8;
-1216x1216 batch 16 -- and one eval forward of the batch-32 inference configuration, with the existing table ignored
+1216x1216 batch 16; the six other multiscale resolutions 512...704 at batch 16 -- and one eval forward of the batch-32
+inference configuration, with the existing table ignored
 (CY_TUNE_CACHE=0) so that everything is re-timed, and writes every choice with its time.  Copy the result to
 complex-yolov4-pytorch_amd/tune_cache/gfx950.json and commit it: it is valid for exactly the kernel sources it was
 measured on (sha inside)."""
@@ -62,6 +63,9 @@ def main():
     if not quick:
         cases += [('train', 'bf16', 16, 608, False), ('train', 'bf16', 16, 608, True), ('eval', 'f16', 32, 608, False),
                   ('train', 'f16', 8, 1024, False), ('train', 'f16', 16, 1216, False), ('train', 'f32', 16, 608, True)]
+        # multiscale training (reference kitti_dataset.py:42-43,225-230: img_size +- 3 x 32 every 10 batches): without these a
+        # new resolution times its candidates at first sight
+        cases += [('train', 'f16', 16, S, False) for S in (512, 544, 576, 640, 672, 704)]
     for kind, dtype, B, S, det in cases:
         t0 = time.time()
         if kind == 'train':
