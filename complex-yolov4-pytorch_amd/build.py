@@ -72,10 +72,57 @@ def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
 
+PLAN_SRC, PLAN_INC = os.path.join(CSRC, 'plan_replay.cpp'), os.path.join(CSRC, 'plan_tramp.inc')
+# entry points that cannot be part of a recorded launch list: the plan machinery itself, and calls that read HOST arrays
+# (their pointers are temporaries of the calling frame)
+_PLAN_SKIP = ('cy_run_plan', 'cy_plan_fn_index', 'cy_plan_fn_nargs', 'cy_event_create', 'cy_event_destroy')
+
+
+def gen_plan_trampolines(header=None, out=None):
+    """include/cyolo_hip.h -> csrc/plan_tramp.inc: one trampoline per int-returning entry point, unpacking cy_run_plan's
+    int64 words (pointers / integers as themselves, floats as double bits) into the C signature, and the name table."""
+    import re
+    text = open(header or os.path.join(INCLUDE, 'cyolo_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+    tramps, table = [], []
+    for m in re.finditer(r'\b(int64_t|int)\s+(cy_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), ' '.join(m.group(3).split())
+        if ret != 'int' or name in _PLAN_SKIP or '_host' in args:
+            continue
+        casts = []
+        if args and args != 'void':
+            for i, a in enumerate(args.split(',')):
+                a = a.strip()
+                ty = a[:re.search(r'[A-Za-z_0-9]+$', a).start()].strip()
+                if '*' in ty or ty == 'cy_stream_t':
+                    casts.append('(%s)a[%d].p' % (ty, i))
+                elif ty in ('float', 'double'):
+                    casts.append('(%s)a[%d].d' % (ty, i))
+                else:
+                    casts.append('(%s)a[%d].i' % (ty, i))
+        tramps.append('static int t_%s(const Word* a) { (void)a; return %s(%s); }' % (name, name, ', '.join(casts)))
+        table.append('    {"%s", t_%s, %d},' % (name, name, len(casts)))
+    body = ('// GENERATED by build.py::gen_plan_trampolines from include/cyolo_hip.h -- do not edit\n' + '\n'.join(tramps) +
+            '\nstatic const Entry kEntries[] = {\n' + '\n'.join(table) + '\n};\n')
+    out = out or PLAN_INC
+    if not os.path.exists(out) or open(out).read() != body:
+        with open(out, 'w') as f:
+            f.write(body)
+    return len(table)
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     hdr_time = max(_mtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS)
     objs, procs = [], []
+    # the launch-list replayer (host code only; not a kernel source: outside tune.sources_sha's glob)
+    gen_plan_trampolines()
+    plan_o = os.path.join(CSRC, 'plan_replay.o')
+    if force or _mtime(plan_o) < max(_mtime(PLAN_SRC), _mtime(PLAN_INC), _mtime(os.path.join(INCLUDE, 'cyolo_hip.h'))):
+        subprocess.check_call([hipcc, '-O2', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC,
+                               '-I' + os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), 'include'),
+                               '-D__HIP_PLATFORM_AMD__', '-x', 'c++',
+                               '-c', PLAN_SRC, '-o', plan_o])
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
@@ -96,6 +143,7 @@ def build(force=False, verbose=False):
             except RuntimeError:
                 os.remove(os.path.join(CSRC, src.replace('.hip', '.o')))     # never link an object that failed the check
                 raise
+    objs.append(plan_o)
     if procs or force or _mtime(LIB) < max(_mtime(o) for o in objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

@@ -399,6 +399,23 @@ int cy_bev_mosaic_targets(float* targets, int nT, const int32_t* tile_of_target,
 int cy_bev_flip_cutout(const float* src, int C, int H, int W, int flip, const int* holes_host, int nholes, float fill,
                        float* out, float* targets, int nT, uint8_t* keep, cy_stream_t s);
 
+/* ------------------------------------------------------------------------------------------------
+ * Stream ordering and recorded launch lists (no reference counterpart: the reference's step is eager PyTorch,
+ * src/train.py:205-235; this is how the ~650 calls of a train step leave the host in one call).
+ * cy_event_*: a hipEvent (timing disabled) as an opaque handle; record on a stream, make another stream wait for it -- the
+ * fork / join of the two-stream backward (weight gradients beside the BatchNorm / dgrad chain), as calls of THIS library so
+ * that they can be part of a recorded list.
+ * cy_run_plan: `prog` = int64 words [fn, nargs, args...] per call (fn from cy_plan_fn_index(entry point name); pointers and
+ * integers as themselves, floats as the bits of a double); re-issues the calls in order.  Returns 0, or the first failing
+ * call's status with its ordinal in *failed_op.  Only int-returning entry points can be recorded. */
+int cy_event_create(void** ev);
+int cy_event_destroy(void* ev);
+int cy_event_record(void* ev, cy_stream_t s);
+int cy_stream_wait_event(cy_stream_t s, void* ev);
+int cy_plan_fn_index(const char* name);
+int cy_plan_fn_nargs(int fn);
+int cy_run_plan(const int64_t* prog, int64_t nwords, int32_t* failed_op);
+
 #ifdef __cplusplus
 }
 #endif

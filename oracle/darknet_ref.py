@@ -84,9 +84,14 @@ class DarknetRef:
         return params, bufs
 
     def forward(self, params, x, targets=None, use_giou_loss=True, training=True, bufs=None,
-                keep=None):
+                keep=None, storage_round=None):
         """Returns (outputs[B,N,7+C], loss or None, [metrics per head]).  ``keep`` (a dict) receives
-        intermediate activations by module index when given."""
+        intermediate activations by module index when given.  ``storage_round`` (a function tensor -> tensor, e.g. a
+        float16 round trip) models 16-BIT STORAGE in this float32 arithmetic: it is applied to every convolution's input,
+        weight and -- for BatchNorm layers -- output (the tensors a half-precision implementation keeps in memory; the
+        head logits stay float32).  The tests use it to tell what 16-bit rounding alone does to the reference's own
+        function from what a kernel adds."""
+        rnd = storage_round if storage_round is not None else (lambda t: t)
         img_size = x.shape[2]
         outs = {}
         heads, metrics = [], []
@@ -97,7 +102,11 @@ class DarknetRef:
                 n = m['n']
                 w = params['models.%d.conv%d.weight' % (i, n)]
                 b = params.get('models.%d.conv%d.bias' % (i, n))
-                x = F.conv2d(x, w, b, m['stride'], m['pad'])
+                if storage_round is not None:      # 16-bit weight COPIES of float32 masters: the gradient stays float32
+                    w = w + (rnd(w.detach()) - w.detach())
+                x = F.conv2d(rnd(x), w, b, m['stride'], m['pad'])
+                if m['bn'] and storage_round is not None:
+                    x = rnd(x)
                 if keep is not None:
                     keep[('raw', i)] = x
                 if m['bn']:

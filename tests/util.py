@@ -80,3 +80,21 @@ def assert_grads_agree(errs, tight=5e-3, frac_tight=0.8, loose=1.0):
     assert not bad, bad
     assert np.median(v) <= tight, ('median', float(np.median(v)))
     assert (v <= tight).mean() >= frac_tight, ('fraction tight', float((v <= tight).mean()))
+
+
+def storage_round(dtype):
+    """tensor -> tensor: a round trip through ``dtype`` (torch.float16 / torch.bfloat16) whose backward rounds the
+    gradient the same way -- 16-bit storage of an activation AND of its gradient, in float32 arithmetic
+    (oracle.darknet_ref.DarknetRef.forward(storage_round=...))."""
+    import torch
+
+    class _Round(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.to(dtype).to(t.dtype)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g.to(dtype).to(g.dtype)
+
+    return lambda t: _Round.apply(t) if t.requires_grad else t.to(dtype).to(t.dtype)

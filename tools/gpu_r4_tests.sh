@@ -2,5 +2,7 @@
 # the round-4 GPU tests with their printed measurements (no -x: every test reports)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/r4b
+python tools/v3tiny_debug.py > gpurun_out/r4b/v3tiny.log 2>&1
 python -m pytest tests/test_gpu_r4.py -q -s -m gpu "$@" > gpurun_out/r4b/tests_r4.log 2>&1; echo "tests rc $?" >> gpurun_out/r4b/tests_r4.log
-grep -E "^(conditioned|v4 608|f32 eval|f16 eval|  rows|  end to end|bench --gpus|v3-tiny|FAILED|ERROR|tests rc|[0-9]+ (passed|failed))" gpurun_out/r4b/tests_r4.log | cut -c1-400
+grep -E "^.?(conditioned|v4 608|f32 eval|f16 eval|  rows|  end to end|  images|bench --gpus|v3-tiny|FAILED|ERROR|tests rc|[0-9]+ (passed|failed))" gpurun_out/r4b/tests_r4.log | cut -c1-450
+tail -14 gpurun_out/r4b/v3tiny.log
