@@ -41,8 +41,83 @@ def parse_header(path=HEADER):
     return protos
 
 
+class PlanRecorder:
+    """Collects the calls of one eager pass as a program for cy_run_plan (include/cyolo_hip.h, csrc/plan_replay.cpp): while
+    it is the library's ``recorder`` every ``_Lib.call`` is executed as usual AND appended as int64 words [fn, nargs, args...]
+    (pointers / integers as themselves, floats as the bits of a double).  ``py(fn)`` cuts the C segment and puts a Python
+    callable between two segments (a hook that has to run on the host at that point of the stream order)."""
+
+    def __init__(self, lib):
+        self.lib, self.items, self._words, self.calls = lib, [], None, 0
+
+    def call(self, name, args):
+        fn = self.lib.fn_index(name)
+        if fn < 0:
+            raise CyoloError('%s cannot be part of a recorded launch list (host-array arguments or not an int entry point)' % name)
+        types = self.lib.protos[name][1]
+        if self._words is None:
+            self._words = []
+            self.items.append(('c', self._words))
+        w = self._words
+        w.append(fn)
+        w.append(len(types))
+        for (ct, _), v in zip(types, args):
+            if ct is ctypes.c_void_p:
+                if v is None:
+                    w.append(0)
+                elif isinstance(v, int):
+                    w.append(v)
+                else:
+                    w.append(v.value or 0)
+            elif ct is ctypes.c_float:
+                w.append(_DBL.unpack(_DBLP.pack(float(v)))[0])
+            else:
+                w.append(int(v))
+        self.calls += 1
+
+    def py(self, fn):
+        self.items.append(('py', fn))
+        self._words = None
+
+    def finish(self):
+        return Program(self.lib, self.items, self.calls)
+
+
+class Program:
+    """A recorded launch list: ``run()`` re-issues it (one cy_run_plan call per C segment, Python hooks in between)."""
+
+    def __init__(self, lib, items, calls):
+        self.lib, self.calls = lib, calls
+        self.items = [(k, (ctypes.c_int64 * len(v))(*v)) if k == 'c' else (k, v) for k, v in items if k == 'py' or v]
+        self._failed = ctypes.c_int32(0)
+
+    def run(self):
+        run, failed = self.lib._dll.cy_run_plan, self._failed
+        for kind, v in self.items:
+            if kind == 'c':
+                rc = run(v, len(v), ctypes.byref(failed))
+                if rc != 0:
+                    raise CyoloError('replayed launch list: call #%d failed with status %d' % (failed.value, rc))
+            else:
+                v()
+
+
+import struct as _struct  # noqa: E402
+
+_DBL, _DBLP = _struct.Struct('<q'), _struct.Struct('<d')
+
+
 class _Lib:
+    recorder = None       # a PlanRecorder while an engine records a pass
+
+    def fn_index(self, name):
+        i = self._fn_index.get(name)
+        if i is None:
+            i = self._fn_index[name] = int(self._dll.cy_plan_fn_index(name.encode()))
+        return i
+
     def __init__(self):
+        self._fn_index = {}
         if not os.path.exists(LIBPATH):
             raise CyoloError('libcyolo_hip.so not built: run `python __graft_entry__.py` (build()) first: ' + LIBPATH)
         self._dll = ctypes.CDLL(LIBPATH)
@@ -57,6 +132,8 @@ class _Lib:
 
     def call(self, name, *args):
         """Call an int-returning entry point; raise on a non-zero status."""
+        if self.recorder is not None:
+            self.recorder.call(name, args)
         rc = getattr(self._dll, name)(*args)
         if rc != 0:
             raise CyoloError('%s failed with status %d' % (name, rc))

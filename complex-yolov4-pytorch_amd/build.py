@@ -73,9 +73,11 @@ def _mtime(p):
 
 
 PLAN_SRC, PLAN_INC = os.path.join(CSRC, 'plan_replay.cpp'), os.path.join(CSRC, 'plan_tramp.inc')
-# entry points that cannot be part of a recorded launch list: the plan machinery itself, and calls that read HOST arrays
-# (their pointers are temporaries of the calling frame)
-_PLAN_SKIP = ('cy_run_plan', 'cy_plan_fn_index', 'cy_plan_fn_nargs', 'cy_event_create', 'cy_event_destroy')
+# entry points that cannot be part of a recorded launch list: the plan machinery itself, and calls whose HOST-array arguments
+# change from call to call (learning rates per step, augmentation rectangles).  The head entry points read host arrays too
+# (anchors, the heads table), but those are per-model constants the operator layer keeps alive (ops.py).
+_PLAN_SKIP = ('cy_run_plan', 'cy_plan_fn_index', 'cy_plan_fn_nargs', 'cy_event_create', 'cy_event_destroy', 'cy_adam_multi',
+              'cy_adam_multi_dev', 'cy_sgd_multi', 'cy_bev_mosaic', 'cy_bev_mosaic_targets', 'cy_bev_flip_cutout')
 
 
 def gen_plan_trampolines(header=None, out=None):
@@ -87,7 +89,7 @@ def gen_plan_trampolines(header=None, out=None):
     tramps, table = [], []
     for m in re.finditer(r'\b(int64_t|int)\s+(cy_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), ' '.join(m.group(3).split())
-        if ret != 'int' or name in _PLAN_SKIP or '_host' in args:
+        if ret != 'int' or name in _PLAN_SKIP:
             continue
         casts = []
         if args and args != 'void':

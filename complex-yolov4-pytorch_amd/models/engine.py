@@ -21,6 +21,12 @@ def _pad32(c):
     return (c + 31) // 32 * 32
 
 
+def _wgrad_rows(rec):
+    """Rows of a weight-gradient slab = channels of the gradient view cy_conv_wgrad is handed: the real channel count of a
+    BatchNorm conv's output (complex_yolov3_tiny.cfg's first layer has 16), the 32-padded staging tensor of a head conv."""
+    return rec['cout'] if rec['bn'] else _pad32(rec['cout'])
+
+
 _PW_DIRECT = ((64, 64), (128, 64), (64, 128), (64, 32), (32, 64))    # (Cin, Cout) of the 1x1 streaming kernel (conv_direct.hip)
 _CONV_TUNE_MEMO = {}      # (kind, shape key) -> best kernel / tile hint, shared by every engine of the process
 # tools/make_tune_cache.py only: lets the process that PRODUCES the persisted table time deterministic engines too (their
@@ -82,15 +88,16 @@ class Engine:
                 if training:
                     max_bnrows = max(max_bnrows, ops.bn_bwd_rows(M, C, dt, self.det) * 2 * C)
             if training:
-                sp = ops.wgrad_split(M, cop, cip, rec['ks'])
+                wr = _wgrad_rows(rec)
+                sp = ops.wgrad_split(M, wr, cip, rec['ks'])
                 # room for the split autotuner (first backward) to move away from the heuristic's choice
                 cap = max(1, min((M + 511) // 512, max(2 * sp, sp + 4), 128))
-                while cap > sp and cap * cop * kk * cip * 4 > (512 << 20):
+                while cap > sp and cap * wr * kk * cip * 4 > (512 << 20):
                     cap -= 1
                 self.wsplit[rec['idx']] = sp
                 self.wsplit_cap[rec['idx']] = max(cap, sp)
                 self.wslab_off[rec['idx']] = max_wpart
-                max_wpart += self.wsplit_cap[rec['idx']] * cop * kk * cip
+                max_wpart += self.wsplit_cap[rec['idx']] * wr * kk * cip
         # binned-atomics tables: zero once, every finaliser leaves its table zeroed for the next layer
         # (the first statistics table and both BN-backward tables share one allocation: a training step zeroes them with ONE
         # fill at the top of the forward pass -- nothing touches the backward tables before the backward pass)
@@ -123,6 +130,21 @@ class Engine:
         # (graphed.GraphedTrainStep) has its pointer baked into its kernel arguments and keeps writing there on every replay
         self._retired_ws = []
         self._wgrad_ev, self._main_stream, self._side_scope = {}, None, None
+        self._main_h = self._side_h = None      # raw stream handles of the pass under way (ops.stream_handle)
+        self._fork_ev = self._join_ev = None    # ops.Event: main -> side before a fold, side -> main at the end of backward
+        # Recorded launch lists (ops.start_recording / cy_run_plan): once every kernel / tile / split choice is made the
+        # calls of a pass are the same from step to step -- static storages, scalars on the device -- so the pass is recorded
+        # once per key (target rows, parameter / gradient buffers, loss scale, stream) and re-issued from C in one call:
+        # the host's share of a step drops from ~12 ms of Python + ctypes to ~2 ms.  Not a hipGraph: a replay IS the eager
+        # launch sequence.  CY_PLAN_REPLAY=0 keeps every pass eager; bench.py's launch brackets (ops.PROFILER) and the
+        # opt-in side-stream heads do too.
+        self.replay = (os.environ.get('CY_PLAN_REPLAY', '1') != '0' and getattr(device, 'type', str(device)) == 'cuda'
+                       and hasattr(ops, 'start_recording') and os.environ.get('CY_HEADS_SIDE', '0') != '1')
+        self._fwd_progs, self._bwd_progs, self._fwd_key = {}, {}, None
+        self.replayed = 0                        # passes issued through cy_run_plan (tests / probes)
+        self._on_module_done = None
+        self._tg_buf = None                      # engine-owned copy of the target rows (a recorded list needs a fixed address)
+        self._gout_buf = torch.zeros(1, **f32) if training else None
         self.fwd_serial = 0
         self._reduce_groups = None
         use_side = training and getattr(device, 'type', str(device)) == 'cuda' and os.environ.get('CY_WGRAD_SIDE_STREAM', '1') != '0'
@@ -184,18 +206,71 @@ class Engine:
             self._sp = 0
             (self._ztab if self.bnpart_pair is not None else self.stats_pair[0]).zero_()
             self._bn_tables_fwd = self.fwd_serial
+        targets = self._own_targets(targets)
         with self._scope():
             ops.nchw_to_nhwc(x, plan.input.C, self.dt, out=self.view(plan.input))
             self.params = params
-            self._pack_all(weights_epoch)
-            if not self._fwd_tuned:
-                self._autotune_fwd()
-            for rec in plan.fwd:
-                getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
+            key = prog = None
+            can = (self.replay and self._fwd_tuned and ops.PROFILER is None and ops.recording() is None
+                   and (not self.training or (self._wgrad_tuned and self._dgrad_tuned)) and (self.training or weights_epoch is not None))
+            if can:
+                key = self._fwd_key = self._forward_key(targets, params, use_giou, img_size, weights_epoch)
+                prog = self._fwd_progs.get(key)
+            else:
+                self._fwd_key = None
+            if prog is not None:
+                if self.training:
+                    self._sp = prog.sp_after
+                prog.run()
+                self.replayed += 1
+            else:
+                rec_on = can and (self.training or weights_epoch == self._pack_epoch)     # (eval: record a pass that packs nothing)
+                if rec_on:
+                    ops.start_recording()
+                try:
+                    self._pack_all(weights_epoch)
+                    if not self._fwd_tuned:
+                        self._autotune_fwd()
+                    for rec in plan.fwd:
+                        getattr(self, '_f_' + rec['op'])(rec, targets, use_giou, img_size)
+                except BaseException:
+                    if rec_on:
+                        ops.stop_recording(keep=False)
+                    raise
+                if rec_on:
+                    prog = ops.stop_recording()
+                    prog.sp_after = self._sp
+                    self._fwd_progs[key] = prog
         if self._heads_on_side:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
             self._heads_on_side = False
         return self.outputs
+
+    def _own_targets(self, targets):
+        """The caller's target rows copied into an engine-owned buffer (a recorded launch list needs them at a fixed address);
+        -> the view of that buffer holding this batch's rows."""
+        if targets is None:
+            return None
+        nT = int(targets.shape[0])
+        if self._tg_buf is None or self._tg_buf.shape[0] < max(nT, 1) or self._tg_buf.shape[1] != targets.shape[1]:
+            if self._tg_buf is not None:
+                self._retired_ws.append(self._tg_buf)
+            self._tg_buf = torch.zeros(max(2 * nT, 256), targets.shape[1], dtype=torch.float32, device=self.device)
+        own = self._tg_buf[:nT]
+        if nT:
+            own.copy_(targets, non_blocking=True)
+        return own
+
+    def _forward_key(self, targets, params, use_giou, img_size, weights_epoch):
+        """Everything a recorded forward pass depends on besides the static storages: target-row count and buffer, the
+        parameter tensors' addresses (conv masters through the pack table's key; the first and last BatchNorm vectors stand
+        for the rest -- optimizers update in place, only .to() / re-assignment moves them), loss variant, image size, stream."""
+        ws = self.plan.convs
+        first, last = self._names(ws[0]), self._names(ws[-1])
+        probe = tuple(params[n].data_ptr() for n in (first[1] + '.weight', first[1] + '.running_mean', last[0] + '.weight') if n in params)
+        pk = tuple(params[self._names(r)[0] + '.weight'].data_ptr() for r in ws)
+        return (None if targets is None else (int(targets.shape[0]), targets.data_ptr()), bool(use_giou), int(img_size), pk, probe,
+                torch.cuda.current_stream(self.device).cuda_stream, None if self.training else weights_epoch)
 
     def _pack_all(self, weights_epoch=None):
         """fp32 master weights -> packed f16/f32 matrices of every conv, one table-driven launch, on every forward.
@@ -234,7 +309,7 @@ class Engine:
         group cut by gradient count held 0.68 ms of slabs, exposed before the optimizer) -- so the groups are cut by slab
         bytes (a quarter of the total each) and the final group only holds the last layers, <= 8 MB of slabs."""
         recs = [b['fwd'] for b in self.plan.bwd if b['op'] in ('conv_bwd', 'head_conv_bwd')]
-        nbytes = [4 * self.wsplit[r['idx']] * _pad32(r['cout']) * r['ks'] * r['ks'] * r['cin_pad'] for r in recs]
+        nbytes = [4 * self.wsplit[r['idx']] * _wgrad_rows(r) * r['ks'] * r['ks'] * r['cin_pad'] for r in recs]
         tail, acc = len(recs) - 1, nbytes[-1] if recs else 0
         while tail > 0 and acc + nbytes[tail - 1] <= (8 << 20):
             tail -= 1
@@ -255,7 +330,7 @@ class Engine:
             items = []
             for rec in g:
                 idx = rec['idx']
-                cop, cip, kk = _pad32(rec['cout']), rec['cin_pad'], rec['ks'] * rec['ks']
+                cop, cip, kk = _wgrad_rows(rec), rec['cin_pad'], rec['ks'] * rec['ks']
                 sp = self.wsplit[idx]
                 off = self.wslab_off[idx]
                 part = self.wpart[off:off + sp * cop * kk * cip]
@@ -428,8 +503,12 @@ class Engine:
         ``loss_scale`` (= act_scale, or act_scale * world so that a plain SUM all-reduce yields the mean).
         on_module_done(idx) is called after the kernels that finish module idx's parameter gradients are queued."""
         assert self.training
-        self.grads, self.gout, self.ls = grads, gout_dev, float(loss_scale)
+        self.grads, self.ls = grads, float(loss_scale)
+        self._gout_buf.copy_(gout_dev.reshape(-1)[:1], non_blocking=True)      # fixed address for the recorded list
+        self.gout = self._gout_buf
         self.act_scale = float(loss_scale if act_scale is None else act_scale)
+        self._on_module_done = on_module_done
+        tuned = self._wgrad_tuned and self._dgrad_tuned
         if not self._wgrad_tuned:
             self._autotune_wgrad()
         if not self._dgrad_tuned:
@@ -437,41 +516,80 @@ class Engine:
         if self._reduce_groups is None or self._reduce_key != grads[next(iter(grads))].data_ptr():
             self._build_reduce_groups()
         flush_at = {g['last']: g for g in self._reduce_groups}
+        on_dev = getattr(self.device, 'type', str(self.device)) == 'cuda'
+        self._main_stream = torch.cuda.current_stream(self.device) if on_dev else None
         if self.side is not None:
-            self._main_stream = torch.cuda.current_stream(self.device)
             self._side_scope = ops.stream_scope(self.side)
+            self._main_h, self._side_h = ops.stream_handle(self._main_stream), ops.stream_handle(self.side)
+            if self._fork_ev is None:
+                self._fork_ev, self._join_ev = ops.Event(), ops.Event()
         if self.bnpart_pair is not None:
             self._bp = 0
             if self._bn_tables_fwd != self.fwd_serial:     # (zeroed by this step's forward pass otherwise)
                 self.bnpart_pair[0].zero_()
                 self.bnpart_pair[1].zero_()
             self._bn_tables_fwd = -1
-        with self._scope():
-            for rec in self.plan.bwd:
-                getattr(self, '_b_' + rec['op'])(rec)
-                if rec['op'] in ('conv_bwd', 'head_conv_bwd'):
-                    g = flush_at.get(rec['fwd']['idx'])
-                    if g is not None:
-                        self._flush_group(g, on_module_done)
-        if self.side is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        key = prog = None
+        can = (self.replay and tuned and on_dev and self._fwd_key is not None and ops.PROFILER is None and ops.recording() is None)
+        if can:
+            key = (self._fwd_key, self._reduce_key, self.ls, self.act_scale, on_module_done is not None, self._main_stream.cuda_stream,
+                   self.side is not None)
+            prog = self._bwd_progs.get(key)
+        if prog is not None:
+            self._bp = prog.bp_after
+            prog.run()
+            self.replayed += 1
+            return
+        if can:
+            ops.start_recording()
+        try:
+            with self._scope():
+                for rec in self.plan.bwd:
+                    getattr(self, '_b_' + rec['op'])(rec)
+                    if rec['op'] in ('conv_bwd', 'head_conv_bwd'):
+                        g = flush_at.get(rec['fwd']['idx'])
+                        if g is not None:
+                            self._flush_group(g)
+                if self.side is not None:      # join: the pass's stream waits for the weight-gradient stream
+                    ops.event_record(self._join_ev, self._side_h)
+                    ops.stream_wait_event(self._main_h, self._join_ev)
+        except BaseException:
+            if can:
+                ops.stop_recording(keep=False)
+            raise
+        if can:
+            prog = ops.stop_recording()
+            prog.bp_after = self._bp
+            self._bwd_progs[key] = prog
 
-    def _flush_group(self, g, on_module_done):
+    def _flush_group(self, g):
         """Fold the split-K slabs of one group of convs into the flat gradient and announce its modules as final.  With
         the side stream this also runs there (after the main stream's BN-parameter gradients of the group, which the
-        side stream waits for), so the main stream never stalls on weight gradients before the end of backward."""
+        side stream waits for), so the main stream never stalls on weight gradients before the end of backward.  The
+        announcement (the data-parallel wrapper's bucketed all-reduce) is host code: in a recorded pass it sits between two
+        C segments and reads the CURRENT backward's hook."""
+        mods = g['mods']
         if self.side is None:
             ops.wgrad_reduce_multi(g['desc'], g['blocks'], 1.0 / self.ls, True)
-            if on_module_done is not None:
-                for idx in g['mods']:
-                    on_module_done(idx)
-            return
-        self.side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.side), ops.stream_scope(self.side):
-            ops.wgrad_reduce_multi(g['desc'], g['blocks'], 1.0 / self.ls, True)
-            if on_module_done is not None:
-                for idx in g['mods']:
-                    on_module_done(idx)
+
+            def announce():
+                for idx in mods:
+                    self._on_module_done(idx)
+        else:
+            ops.event_record(self._fork_ev, self._main_h)
+            ops.stream_wait_event(self._side_h, self._fork_ev)
+            with self._side_scope:
+                ops.wgrad_reduce_multi(g['desc'], g['blocks'], 1.0 / self.ls, True)
+
+            def announce():
+                with torch.cuda.stream(self.side):
+                    for idx in mods:
+                        self._on_module_done(idx)
+        if self._on_module_done is not None:
+            announce()
+            rec = ops.recording() if hasattr(ops, 'recording') else None
+            if rec is not None:
+                rec.py(announce)
 
     def _autotune_wgrad(self):
         """Pick the split-K factor of every weight-gradient launch (once, at the first backward; shapes are static): a hit in
@@ -489,7 +607,7 @@ class Engine:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for rec in self.plan.convs:
             idx = rec['idx']
-            cop, cip, kk = _pad32(rec['cout']), rec['cin_pad'], rec['ks'] * rec['ks']
+            cop, cip, kk = _wgrad_rows(rec), rec['cin_pad'], rec['ks'] * rec['ks']
             dy = self.head_tmp[heads[id(rec)]] if id(rec) in heads else self.view(rec['out'], grad=True)
             xv = self.view(rec['x'])
             key = ('wgrad', self.dt, dy.N, dy.H, dy.W, dy.C, dy.ld, xv.H, xv.W, xv.C, xv.ld, rec['ks'], rec['stride'], rec['pad'])
@@ -720,9 +838,9 @@ class Engine:
             # stream does not have to follow)
             ev = self._wgrad_ev.get(rec['idx'])
             if ev is None:
-                ev = self._wgrad_ev[rec['idx']] = torch.cuda.Event()
-            ev.record(self._main_stream)
-            self.side.wait_event(ev)
+                ev = self._wgrad_ev[rec['idx']] = ops.Event()
+            ops.event_record(ev, self._main_h)
+            ops.stream_wait_event(self._side_h, ev)
             with self._side_scope:
                 self._wgrad_launch(rec, dy, xv)
             return
@@ -731,7 +849,7 @@ class Engine:
     def _wgrad_launch(self, rec, dy, xv):
         idx = rec['idx']
         cname, _ = self._names(rec)
-        cop, cip = _pad32(rec['cout']), rec['cin_pad']
+        cop, cip = _wgrad_rows(rec), rec['cin_pad']
         sp = self.wsplit[idx]
         off = self.wslab_off[idx]
         part = self.wpart[off:off + sp * cop * rec['ks'] * rec['ks'] * cip]

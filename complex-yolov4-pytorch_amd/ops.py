@@ -125,6 +125,56 @@ class stream_scope:
         return False
 
 
+class Event:
+    """A hipEvent owned by the library (cy_event_create): the fork / join primitive of the two-stream backward, issued through
+    the C ABI so that it can be part of a recorded launch list (torch.cuda.Event records cannot)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        lib().call('cy_event_create', ctypes.c_void_p(ctypes.addressof(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            lib().raw('cy_event_destroy')(self.handle)
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def stream_handle(stream):
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+def event_record(ev, handle):
+    lib().call('cy_event_record', ev.handle, handle)
+
+
+def stream_wait_event(handle, ev):
+    lib().call('cy_stream_wait_event', handle, ev.handle)
+
+
+def start_recording():
+    """Every operator call from here to stop_recording() is executed AND recorded.  -> the recorder (``.py(fn)`` inserts a host
+    hook).  One recording at a time per process."""
+    from ._lib import PlanRecorder
+    L = lib()
+    if L.recorder is not None:
+        raise CyoloError('a launch list is already being recorded')
+    L.recorder = PlanRecorder(L)
+    return L.recorder
+
+
+def stop_recording(keep=True):
+    """-> the recorded Program (None with keep=False: a pass that raised)."""
+    L = lib()
+    rec, L.recorder = L.recorder, None
+    return rec.finish() if (keep and rec is not None) else None
+
+
+def recording():
+    return lib().recorder
+
+
 def _stream():
     h = getattr(_TLS, 'handle', None)
     return h if h is not None else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -505,9 +555,22 @@ def _farr(vals):
     return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
 
 
+_CONST_FARR = {}
+
+
+def _const_farr(vals):
+    """A host float array that lives as long as the process (per-model constants such as anchors): a launch list recorded with
+    its address (cy_run_plan) stays valid."""
+    key = tuple(float(v) for v in vals)
+    a = _CONST_FARR.get(key)
+    if a is None:
+        a = _CONST_FARR[key] = _farr(key)
+    return a
+
+
 def yolo_decode(logits, B, G, A, C, anchors_wh, img_size, out, rows_total, row_offset):
     flat = [v for a in anchors_wh for v in a[:2]]
-    lib().call('cy_yolo_decode', _p(logits), B, G, A, C, _farr(flat), float(img_size), _p(out), rows_total, row_offset,
+    lib().call('cy_yolo_decode', _p(logits), B, G, A, C, _const_farr(flat), float(img_size), _p(out), rows_total, row_offset,
                _stream())
 
 
@@ -523,7 +586,7 @@ def yolo_loss_workspace(B, G, A, C, nT):
 def yolo_loss(logits, B, G, A, C, targets, anchors, img_size, ignore_thresh, use_giou, workspace, metrics, dlogits):
     nT = 0 if targets is None else targets.shape[0]
     flat = [v for a in anchors for v in a[:4]]
-    lib().call('cy_yolo_loss', _p(logits), B, G, A, C, _p(targets) if nT else None, nT, _farr(flat), float(img_size),
+    lib().call('cy_yolo_loss', _p(logits), B, G, A, C, _p(targets) if nT else None, nT, _const_farr(flat), float(img_size),
                float(ignore_thresh), int(bool(use_giou)), _p(workspace), _p(metrics), _p(dlogits), _stream())
 
 

@@ -130,6 +130,64 @@ def wgrad_case(out, dt, N, Ci, H, Co, ks, st, split):
         json.dump(dict(grad=gw.flatten().cpu().tolist()), f)
 
 
+def replay_ddp(out):
+    """Recorded launch lists under the data-parallel wrapper (CY_DDP_FORCE=1, nccl, one rank): seven Adam steps of the
+    deterministic f16 model -- two of them 2-micro-step accumulations under no_sync() -- with the passes replayed from C
+    (default) and issued eagerly (CY_PLAN_REPLAY=0): parameters bit-identical, the same all-reduce calls per step."""
+    os.environ['CY_DDP_FORCE'] = '1'
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
+    os.environ['RANK'], os.environ['WORLD_SIZE'] = '0', '1'
+    import torch
+    import torch.distributed as dist
+    import complex_yolov4_pytorch_amd.synthetic as syn
+    from complex_yolov4_pytorch_amd.optim import FusedAdam
+    from complex_yolov4_pytorch_amd.parallel import RcclDataParallel, accumulate
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', device_id=dev)
+    B, S = 4, 608
+    batches = [(syn.bev_images(B, S, seed=51 + i).to(dev), syn.targets(B, 6, S, seed=51 + i).to(dev)) for i in range(3)]
+    plan = [1, 1, 1, 2, 1, 2, 1]             # micro-batches per optimizer step
+    res = {}
+    for mode in ('replay', 'eager'):
+        os.environ['CY_PLAN_REPLAY'] = '1' if mode == 'replay' else '0'
+        model = _model('f16', deterministic=True)
+        net = RcclDataParallel(model)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        calls, per_step = [], []
+        orig = dist.all_reduce
+
+        def spy(t, *a, **k):
+            calls.append(int(t.numel()))
+            return orig(t, *a, **k)
+        dist.all_reduce = spy
+        losses, k = [], 0
+        for micro in plan:
+            opt.zero_grad(set_to_none=True)
+            n0 = len(calls)
+            for i in range(micro):
+                with accumulate(net, i, micro):
+                    loss, _ = net(*batches[k % 3])
+                    loss.backward()
+                k += 1
+            opt.step()
+            per_step.append(calls[n0:])
+            losses.append(float(loss.detach()))
+        dist.all_reduce = orig
+        torch.cuda.synchronize()
+        eng = next(iter(model._engines.values()))
+        res[mode] = dict(losses=losses, params=_sha(torch.cat([p.detach().reshape(-1) for p in model.parameters()])),
+                         bn=_sha(torch.cat([b.detach().float().reshape(-1) for b in model.buffers()])), per_step=per_step,
+                         replayed=int(eng.replayed), programs=(len(eng._fwd_progs), len(eng._bwd_progs)))
+        model.release_engines()
+        del opt, net, model
+        torch.cuda.empty_cache()
+    dist.destroy_process_group()
+    with open(out, 'w') as f:
+        json.dump(res, f)
+
+
 if __name__ == '__main__':
     job, args = sys.argv[1], sys.argv[2:]
-    {'det_hash': det_hash, 'rccl': rccl, 'wgrad_case': wgrad_case}[job](*args)
+    {'det_hash': det_hash, 'rccl': rccl, 'wgrad_case': wgrad_case, 'replay_ddp': replay_ddp}[job](*args)

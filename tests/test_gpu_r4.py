@@ -277,6 +277,15 @@ def test_inference_b32_608_against_reference(golden, dtype):
               'reference arithmetic: median %.2e p99 %.2e max %.2e' % (stats(mine) + stats(ideal)))
         for a, b in zip(stats(mine)[:2], stats(ideal)[:2]):
             assert a <= 1.5 * b, (stats(mine), stats(ideal))
+        # ... which is why the candidate set of a confidence threshold in the tail is not comparable in f16 on this net: ideal
+        # storage changes it as much as the device path does
+        thr0 = float(g['conf_thresh'][0])
+        c32 = o32[..., 6] >= thr0
+        d_ideal = int(((o16[..., 6] >= thr0) ^ c32).sum())
+        d_mine = int(((out[:2, :, 6].cpu() >= thr0) ^ c32).sum())
+        print('  images 0-1: rows on the other side of the confidence threshold than in float32: device f16 %d, ideal f16 storage %d (of %d candidates)'
+              % (d_mine, d_ideal, int(c32.sum())))
+        assert d_mine <= 1.5 * d_ideal + 8
     # (2) threshold crossings
     thr = float(g['conf_thresh'][0])
     mine = set(torch.nonzero(flat[:, 6] >= thr).reshape(-1).cpu().tolist())
@@ -393,6 +402,87 @@ def test_graph_replay_survives_head_workspace_growth_and_checkpoints_the_step_co
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     for k, v in runs[0][1].items():
         assert torch.equal(v, runs[1][1][k]), k
+
+
+# ---- recorded launch lists (cy_run_plan) ----------------------------------------------------------------------------------------
+def test_replayed_launch_lists_equal_eager_steps(monkeypatch):
+    """the passes of a step re-issued from C (ops.start_recording -> cy_run_plan) against the same steps
+    issued call by call from Python, deterministic mode: losses, parameters and BatchNorm running statistics bit-identical over
+    nine Adam steps with three target-row counts (a new count records a new list; a count seen before replays its old one, also
+    after the head workspace has grown in between) and a learning-rate change."""
+    from complex_yolov4_pytorch_amd.optim import FusedAdam
+    S = 416
+    mk = lambda seed, per: (syn.bev_images(2, S, seed=seed).to(DEV), syn.targets(2, per, S, seed=seed).to(DEV))
+    seq = [mk(100, 6), mk(101, 6), mk(102, 6), mk(103, 5), mk(104, 6), mk(105, 40), mk(106, 6), mk(107, 5), mk(108, 40)]
+    runs = {}
+    for mode in ('replay', 'eager'):
+        monkeypatch.setenv('CY_PLAN_REPLAY', '1' if mode == 'replay' else '0')
+        model = _model('complex_yolov4.cfg', 'f16', deterministic=True)
+        model.train()
+        opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        losses = []
+        for i, (x, tg) in enumerate(seq):
+            if i == 4:
+                for g in opt.param_groups:
+                    g['lr'] = 3e-4
+            opt.zero_grad(set_to_none=True)
+            loss, out = model(x, tg)
+            loss.backward()
+            opt.step()
+            losses.append((float(loss.detach()), float(out.abs().sum())))
+        torch.cuda.synchronize()
+        eng = next(iter(model._engines.values()))
+        runs[mode] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, eng.replayed,
+                      (len(eng._fwd_progs), len(eng._bwd_progs)))
+        model.release_engines()
+        del opt, model
+    assert runs['eager'][2] == 0 and runs['eager'][3] == (0, 0)
+    # step 1 tunes, step 2 records (12 rows), step 3 replays, step 4 records (10 rows), 5 replays 12, 6 records 80, 7-9 replay
+    assert runs['replay'][3] == (3, 3), runs['replay'][3]
+    assert runs['replay'][2] == 2 * 5, runs['replay'][2]
+    assert runs['replay'][0] == runs['eager'][0], (runs['replay'][0], runs['eager'][0])
+    for k, v in runs['eager'][1].items():
+        assert torch.equal(v, runs['replay'][1][k]), k
+
+
+def test_replayed_inference_equals_eager(monkeypatch):
+    """The eval engine with static_eval_weights: the forward after the weight pack is recorded, the following ones replay it;
+    outputs bit-identical to the eager engine's, and a parameter change (mark_weights_dirty) re-packs instead of replaying a
+    stale list."""
+    outs = {}
+    x = syn.bev_images(4, 608, seed=9).to(DEV)
+    for mode in ('replay', 'eager'):
+        monkeypatch.setenv('CY_PLAN_REPLAY', '1' if mode == 'replay' else '0')
+        model = _model('complex_yolov4.cfg', 'f16')
+        model.eval()
+        model.cpu_outputs = False
+        model.static_eval_weights = True
+        with torch.no_grad():
+            a = [model(x).clone() for _ in range(4)]
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.mul_(1.01)
+            model.mark_weights_dirty()
+            b = [model(x).clone() for _ in range(3)]
+        eng = next(iter(model._engines.values()))
+        outs[mode] = (a, b, eng.replayed)
+        model.release_engines()
+        del model
+    assert outs['eager'][2] == 0 and outs['replay'][2] >= 3
+    for i in range(4):
+        assert torch.equal(outs['replay'][0][i], outs['eager'][0][0])
+    for i in range(3):
+        assert torch.equal(outs['replay'][1][i], outs['eager'][1][0])
+    assert not torch.equal(outs['eager'][0][0], outs['eager'][1][0])
+
+
+def test_replay_under_the_data_parallel_wrapper(tmp_path):
+    from tests.test_gpu_r3 import _worker
+    r = _worker('replay_ddp', tmp_path, 'replay_ddp', timeout=900)
+    a, b = r['replay'], r['eager']
+    assert b['replayed'] == 0 and a['replayed'] >= 8, (a['replayed'], a['programs'])
+    assert a['losses'] == b['losses'] and a['params'] == b['params'] and a['bn'] == b['bn']
+    assert a['per_step'] == b['per_step'] and all(len(c) >= 2 for c in a['per_step'])      # bucketed all-reduces every step
 
 
 # ---- bench.py --gpus N ---------------------------------------------------------------------------------------------------------
