@@ -67,6 +67,8 @@ class PlanRecorder:
                     w.append(0)
                 elif isinstance(v, int):
                     w.append(v)
+                elif isinstance(v, ctypes.Array):       # a host array the caller keeps alive (per-model constants: anchors)
+                    w.append(ctypes.addressof(v))
                 else:
                     w.append(v.value or 0)
             elif ct is ctypes.c_float:
