@@ -427,10 +427,11 @@ int dispatch_tiles(const IgemmParams& p, hipStream_t s) {
 // one launch: the pipelined kernel when the shape qualifies, else the 4-wave kernels of this file
 int dispatch(const IgemmParams& p, int dtype, hipStream_t s) {
     int used = 0;
-    int rc = cy_direct_try(p, dtype, s, &used);
+    int rc = (p.flags & CY_CONV_BN_FUSED) ? 0 : cy_direct_try(p, dtype, s, &used);
     if (rc || used) return rc;
     rc = cy_pipe_try(p, dtype, s, &used);
     if (rc || used) return rc;
+    if (p.flags & CY_CONV_BN_FUSED) return CY_ERR_UNSUPPORTED;   // two-phase epilogue: the pipelined kernel, one round, or not at all
     if (p.flags & CY_CONV_BNBWD_SUMS) return CY_ERR_ARG;   // only the pipelined kernel has that epilogue
     if (dtype == CY_F16) return dispatch_tiles<f16>(p, s);
     if (dtype == CY_BF16) return dispatch_tiles<bf16>(p, s);
@@ -454,7 +455,7 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
                            int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags,
                            const float* bias, float* stats_part, int* stats_rows_host, const float* aff_scale,
                            const float* aff_shift, int act, const void* res, int ldres, cy_stream_t s,
-                           const float* bn_mean = nullptr, const float* bn_invstd = nullptr) {
+                           const float* bn_mean = nullptr, const float* bn_invstd = nullptr, const IgemmParams* fuse = nullptr) {
     const int ch = dtype == CY_F32 ? 4 : 8;
     if (!g || !w || !out || (dtype != CY_F16 && dtype != CY_BF16 && dtype != CY_F32)) return CY_ERR_ARG;
     if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2) || GC % ch || ldg % ch) return CY_ERR_ARG;
@@ -462,6 +463,13 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
     if ((flags & CY_CONV_STATS_DET) && !(flags & (CY_CONV_STATS | CY_CONV_BNBWD_SUMS))) return CY_ERR_ARG;
     if (!(flags & CY_CONV_BIAS_F32OUT) && (ldo % 4)) return CY_ERR_ARG;
     IgemmParams p;
+    p.o2 = nullptr; p.ldo2 = 0; p.bn_gamma = p.bn_beta = nullptr; p.bn_rmean = p.bn_rvar = nullptr; p.bn_nbt = nullptr;
+    p.bn_momentum = p.bn_eps = 0.f; p.bn_vec = p.bn_zero = nullptr; p.bn_zero_n = 0; p.ticket = nullptr;
+    if (fuse) {
+        p.o2 = fuse->o2; p.ldo2 = fuse->ldo2; p.bn_gamma = fuse->bn_gamma; p.bn_beta = fuse->bn_beta; p.bn_rmean = fuse->bn_rmean;
+        p.bn_rvar = fuse->bn_rvar; p.bn_nbt = fuse->bn_nbt; p.bn_momentum = fuse->bn_momentum; p.bn_eps = fuse->bn_eps;
+        p.bn_vec = fuse->bn_vec; p.bn_zero = fuse->bn_zero; p.bn_zero_n = fuse->bn_zero_n; p.ticket = fuse->ticket;
+    }
     p.g = (const unsigned char*)g; p.w = (const unsigned char*)w; p.o = (unsigned char*)out;
     p.bias = bias; p.stats = stats_part;
     p.aff_scale = aff_scale; p.aff_shift = aff_shift; p.act = act; p.res = (const unsigned char*)res; p.ldres = ldres;
@@ -557,6 +565,27 @@ extern "C" int cy_conv_bn_act_eval(const void* g, int N, int GH, int GW, int GC,
     if (flags & ~CY_CONV_TILE(15)) return CY_ERR_ARG;      // only the kernel / tile hint is accepted here
     return conv_igemm_impl(g, N, GH, GW, GC, ldg, w, wrows, out, OH, OW, OC, ldo, ks, stride, pad, dtype,
                            CY_CONV_AFFINE_ACT | flags, nullptr, nullptr, nullptr, scale, shift, act, res, ldres, s);
+}
+
+extern "C" int cy_conv_bn_act_train(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* raw,
+                                    int OH, int OW, int OC, int ldraw, void* out, int ldout, const void* res, int ldres, int ks,
+                                    int stride, int pad, int dtype, int flags, float* stats_bins, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, void* num_batches_tracked,
+                                    float momentum, float eps, float* vec, float* zero_table, int zero_n, int act,
+                                    int32_t* ticket, cy_stream_t s) {
+    CY_ENTER();
+    if (flags & ~CY_CONV_TILE(15)) return CY_ERR_ARG;      // only the kernel / tile hint is accepted here
+    if (!out || !stats_bins || !gamma || !beta || !vec || !ticket || (zero_n > 0 && !zero_table) || zero_table == stats_bins ||
+        (running_mean && !running_var) || ldout % 8 || (res && ldres % 8))
+        return CY_ERR_ARG;
+    if (dtype != CY_F16 && dtype != CY_BF16) return CY_ERR_UNSUPPORTED;
+    IgemmParams f;
+    f.o2 = (unsigned char*)out; f.ldo2 = ldout; f.bn_gamma = gamma; f.bn_beta = beta; f.bn_rmean = running_mean;
+    f.bn_rvar = running_var; f.bn_nbt = (long long*)num_batches_tracked; f.bn_momentum = momentum; f.bn_eps = eps; f.bn_vec = vec;
+    f.bn_zero = zero_table; f.bn_zero_n = zero_n; f.ticket = ticket;
+    return conv_igemm_impl(g, N, GH, GW, GC, ldg, w, wrows, raw, OH, OW, OC, ldraw, ks, stride, pad, dtype,
+                           CY_CONV_STATS | CY_CONV_BN_FUSED | flags, nullptr, stats_bins, nullptr, nullptr, nullptr, act, res, ldres, s,
+                           nullptr, nullptr, &f);
 }
 
 extern "C" int cy_conv_dgrad_bn_sums(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows,

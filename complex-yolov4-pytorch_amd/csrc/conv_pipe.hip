@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
     if (is_loader) {   // the loaders hold no results; they only keep the block's barrier count whole
         if (p.flags & CY_CONV_STATS) { __syncthreads(); __syncthreads(); }
         if (p.flags & CY_CONV_BNBWD_SUMS) __syncthreads();
+        if (p.flags & CY_CONV_BN_FUSED) { __syncthreads(); __syncthreads(); __syncthreads(); }
         return;
     }
 
@@ -327,6 +328,17 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
         __syncthreads();
     }
 
+    // CY_CONV_BN_FUSED (cy_conv_bn_act_train): BatchNorm with BATCH statistics + activation in this launch.  Phase 1 ends
+    // here: this block's sums are on their way into the bins.  Wait until they have been performed (vmcnt counts atomics on
+    // gfx9), then ARRIVE at the grid's ticket; the pre-BN tile is stored below while the other blocks arrive.
+    const bool bnf = (p.flags & CY_CONV_BN_FUSED) != 0;
+    const int nblk_all = p.mtiles * p.ntiles;
+    if (bnf) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
     if (p.flags & CY_CONV_AFFINE_ACT) {
         typedef T rx4 __attribute__((ext_vector_type(4)));
         const T* resrow[TJ];     // the shortcut operand has the output's pixel indexing (its own channel stride)
@@ -375,6 +387,140 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
         constexpr int CPR = ROWB / 16;           // 16-byte chunks per row
         constexpr int WROWS = BM / WM;
         unsigned char* wt = smem + wave * (WROWS * ROWB);
+        if (bnf) {
+            // (its own copy of the plain store loop, and a return: the accumulators stay live across the grid wait here, which
+            // the general path below -- whose fan-in / sums prefetches reuse their registers -- must not pay for)
+            constexpr int RPI2 = 64 / CPR, NIT2 = WROWS / RPI2;
+            const unsigned opix = (unsigned)p.ldo * (unsigned)sizeof(T);      // bytes per pixel row of the pre-BN tensor
+            auto store_rows = [&](unsigned char* base, unsigned pixbytes) {     // LDS tile -> 16-byte stores, 128 B per pixel
+#pragma unroll
+                for (int t = 0; t < NIT2; ++t) {
+                    const int row = t * RPI2 + lane / CPR, c = lane % CPR;
+                    const unsigned ob = orow[pw + row];
+                    const int co = co_w + c * 8;
+                    const tx8 v = *reinterpret_cast<const tx8*>(wt + row * ROWB + ((c ^ (row & (CPR - 1) & 7)) * 16));
+                    if (ob == 0xFFFFFFFFu || co >= p.OC) continue;
+                    T* dst = reinterpret_cast<T*>(base + (size_t)(ob / opix) * pixbytes) + co;
+                    if (co + 8 <= p.OC) {
+                        *reinterpret_cast<tx8*>(dst) = v;
+                    } else {
+                        for (int e = 0; e < 8 && co + e < p.OC; ++e) dst[e] = v[e];
+                    }
+                }
+            };
+            // ---- the pre-BN tile (kept for the backward pass), while the other blocks arrive ---------------------------------
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        tx4 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[r] = (T)acc[i][j][4 * g + r];
+                        const int row = j * 32 + (lane & 31);
+                        const int ck = (i * 4 + g) ^ (row & (CPR - 1) & 7);
+                        *reinterpret_cast<tx4*>(wt + row * ROWB + ck * 16 + half * 8) = h;
+                    }
+            store_rows(p.o, opix);
+            // ---- phase 2: wait for the grid, fold the bins, normalise + activate the accumulators, store the output ----------
+            if (tid == 0) {
+                // every block of the launch is resident (the host checked grid <= CUs x occupancy), so the wait is bounded by
+                // the slowest block's main loop; the iteration cap only turns a broken assumption into an error flag
+                // (ticket[2]) instead of a hung GPU
+                int spins = 0;
+                while (__hip_atomic_load(p.ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nblk_all) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > (1 << 22)) {
+                        __hip_atomic_store(p.ticket + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                // the last block to leave puts the ticket back for the next launch (every block has seen it full by then)
+                if (__hip_atomic_fetch_add(p.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk_all - 1) {
+                    __hip_atomic_store(p.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.ticket + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            float* bnv = reinterpret_cast<float*>(smem + 8 * (WROWS * ROWB));      // [2][BN]: scale, shift (behind the store tiles)
+            static_assert(8 * WROWS * ROWB + 2 * BN * 4 <= NST * STAGE, "the BN vectors fit behind the store tiles");
+            if (tid < BN) {
+                // thread t owns channel tn * BN + t: bins in index order, double accumulation -- cy_bn_act_fwd_fused's arithmetic
+                const int c = tn * BN + tid;
+                float sc = 0.f, sh = 0.f;
+                if (c < p.OC) {
+                    double sm = 0.0, sq = 0.0;
+#pragma unroll
+                    for (int b = 0; b < CY_STAT_BINS; ++b) {
+                        sm += (double)__hip_atomic_load(p.stats + ((size_t)b * 2) * p.OC + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sq += (double)__hip_atomic_load(p.stats + ((size_t)b * 2 + 1) * p.OC + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const double cnt = (double)p.M;
+                    const double m = sm / cnt;
+                    double var = sq / cnt - m * m;
+                    if (var < 0.0) var = 0.0;
+                    const float is = (float)(1.0 / sqrt(var + (double)p.bn_eps));
+                    sc = p.bn_gamma[c] * is;
+                    sh = p.bn_beta[c] - (float)m * sc;
+                    if (tm == 0) {
+                        p.bn_vec[c] = (float)m;
+                        p.bn_vec[p.OC + c] = is;
+                        p.bn_vec[2 * p.OC + c] = sc;
+                        p.bn_vec[3 * p.OC + c] = sh;
+                        if (p.bn_rmean) {
+                            const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+                            p.bn_rmean[c] = (1.f - p.bn_momentum) * p.bn_rmean[c] + p.bn_momentum * (float)m;
+                            p.bn_rvar[c] = (1.f - p.bn_momentum) * p.bn_rvar[c] + p.bn_momentum * (float)unb;
+                        }
+                        if (p.bn_nbt && c == 0) *p.bn_nbt += 1;
+                    }
+                }
+                bnv[tid] = sc;
+                bnv[BN + tid] = sh;
+            }
+            for (int i = lid * 512 + tid; i < p.bn_zero_n; i += nblk_all * 512) p.bn_zero[i] = 0.f;   // the other table of the pair
+            __syncthreads();
+            typedef T rx4 __attribute__((ext_vector_type(4)));
+            const T* resrow[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const unsigned ob = orow[pw + j * 32 + (lane & 31)];
+                resrow[j] = (p.res && ob != 0xFFFFFFFFu) ? reinterpret_cast<const T*>(p.res) + (size_t)(ob / opix) * p.ldres : nullptr;
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = cw + i * 32 + 8 * g + 4 * half;
+                    const int co = tn * BN + cl;
+                    const f32x4 sc4 = *reinterpret_cast<const f32x4*>(bnv + cl), sh4 = *reinterpret_cast<const f32x4*>(bnv + BN + cl);
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        float zz[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // (the accumulator through the storage type first: what the separate pass reads back from `raw`)
+                            const float z = (float)(T)acc[i][j][4 * g + r] * sc4[r] + sh4[r];
+                            const float zm = mish_f<true>(z), zl = z > 0.f ? z : 0.1f * z;
+                            zz[r] = p.act == CY_ACT_MISH ? zm : (p.act == CY_ACT_LEAKY ? zl : z);
+                        }
+                        if (resrow[j] && co + 3 < p.OC) {
+                            const rx4 rv = *reinterpret_cast<const rx4*>(resrow[j] + co);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) zz[r] += (float)rv[r];
+                        }
+                        tx4 h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[r] = (T)zz[r];
+                        const int row = j * 32 + (lane & 31);
+                        const int ck = (i * 4 + g) ^ (row & (CPR - 1) & 7);
+                        *reinterpret_cast<tx4*>(wt + row * ROWB + ck * 16 + half * 8) = h;
+                    }
+                }
+            store_rows(p.o2, (unsigned)p.ldo2 * (unsigned)sizeof(T));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -532,6 +678,19 @@ int pipe_launch(const IgemmParams& p0, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
+    if (p.flags & CY_CONV_BN_FUSED) {
+        // the two-phase epilogue waits for the whole grid: every block must be resident at once
+        static int capacity = -1;
+        if (capacity < 0) {
+            int per_cu = 0, dev = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&igemm_pipe_kernel<T, BM, BN, WN, NST, EPI_LDS, LOADERS>),
+                                                             512 + 64 * LOADERS, smem) != hipSuccess ||
+                hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                return CY_ERR_UNSUPPORTED;
+            capacity = per_cu * cus;
+        }
+        if (!EPI_LDS || p.mtiles * p.ntiles > capacity) return CY_ERR_UNSUPPORTED;
+    }
     hipLaunchKernelGGL((igemm_pipe_kernel<T, BM, BN, WN, NST, EPI_LDS, LOADERS>), dim3(p.mtiles * p.ntiles), dim3(512 + 64 * LOADERS), smem, s, p);
     CY_LAUNCH_CHECK();
     return 0;
@@ -546,8 +705,8 @@ int pipe_dispatch(const IgemmParams& p, int cap, int bn, int variant, hipStream_
     // no kernel of the train step may use scratch memory, see build.py: that capacity always stores through LDS)
 #define CY_PIPE(BM_, BN_, WN_, NST_)                                                           \
     if (cap == BM_ && bn == BN_) {                                                             \
-        if (p.flags & CY_CONV_BNBWD_SUMS) {                                                                    \
-            if (variant == 1) return CY_ERR_ARG;   /* the sums live in the LDS-transposed store path */          \
+        if (p.flags & (CY_CONV_BNBWD_SUMS | CY_CONV_BN_FUSED)) {                                               \
+            if (variant == 1) return CY_ERR_ARG;   /* the sums / phase 2 live in the LDS-transposed store path */ \
         } else if constexpr (!(BM_ == 384 && BN_ == 128)) {                                                     \
             if (variant == 1 || (p.flags & CY_CONV_ACCUM)) return pipe_launch<T, BM_, BN_, WN_, NST_, false>(p, s); \
         }                                                                                                      \
@@ -615,7 +774,8 @@ int cy_pipe_try(const cyk::IgemmParams& p0, int dtype, hipStream_t s, int* used)
     int hint = (p0.flags >> CY_CONV_TILE_SHIFT) & 15;
     if (hint > 9) hint = 0;          // 10: the direct kernels (conv_direct.hip); a call they do not take is an ordinary one here
     if (g_pipe_mode == 0 || hint == 1 || (dtype != CY_F16 && dtype != CY_BF16)) return 0;
-    if (g_pipe_mode == 1 && hint == 0 && !(p0.flags & (CY_CONV_AFFINE_ACT | CY_CONV_BNBWD_SUMS))) return 0;
+    if (g_pipe_mode == 1 && hint == 0 && !(p0.flags & (CY_CONV_AFFINE_ACT | CY_CONV_BNBWD_SUMS | CY_CONV_BN_FUSED))) return 0;
+    if ((p0.flags & CY_CONV_BN_FUSED) && (p0.ldo2 % 8 || ((uintptr_t)p0.o2 & 15) || (p0.flags & (CY_CONV_ACCUM | CY_CONV_TRANSPOSED)))) return 0;
     if ((p0.flags & CY_CONV_BNBWD_SUMS) && (p0.ldres % 8 || ((uintptr_t)p0.res & 15))) return 0;
     if (p0.GC % 64 || !p0.x_bias || (p0.flags & CY_CONV_BIAS_F32OUT) || p0.OC % 8 || p0.ldo % 8) return 0;
     if (((uintptr_t)p0.o & 15) || (p0.res && (p0.ldres % 4 || ((uintptr_t)p0.res & 7)))) return 0;

@@ -44,6 +44,20 @@ struct IgemmParams {
     // tile index & 3 = class (heaviest first: 4, 2, 2, 1 taps for 3x3 / pad 1), every class over M pixels of its own OHc x OWc
     // sub-lattice (the host merges only when the four sub-lattices are congruent, i.e. OH and OW even).  1: an ordinary launch.
     int ncls;
+    // CY_CONV_BN_FUSED epilogue (conv_pipe.hip, cy_conv_bn_act_train): o / ldo = the pre-BN tensor, o2 / ldo2 = the activated
+    // output, res / ldres = the shortcut operand, stats = the (sum, sumsq) bins; BatchNorm parameters and state below
+    unsigned char* o2;
+    int ldo2;
+    const float* bn_gamma;
+    const float* bn_beta;
+    float* bn_rmean;
+    float* bn_rvar;
+    long long* bn_nbt;
+    float bn_momentum, bn_eps;
+    float* bn_vec;
+    float* bn_zero;
+    int bn_zero_n;
+    int* ticket;
 };
 
 // What a block needs to know about ITS pixel lattice and taps: the launch's own (ordinary launches, one parity class per

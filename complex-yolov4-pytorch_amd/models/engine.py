@@ -42,6 +42,12 @@ class Engine:
         # in a fixed order -- two runs of the same step are bit-identical.  Costs larger tables and slower folds.
         self.det = bool(deterministic)
         self._fwd_tile, self._dgrad_tile, self._fwd_tuned, self._dgrad_tuned = {}, {}, False, False
+        # conv idx -> tile hint of its two-phase conv + BN + activation launch (ops.conv_bn_act_train): the layers whose grid
+        # is one co-resident round, where the first forward timed it against conv + the separate BN / activation pass.
+        # CY_CONV_BN_FUSED: 0 never, 1 (default) timed, 2 wherever the kernel takes the launch
+        self._fwd_fused = {}
+        self.conv_bn_fused = int(os.environ.get('CY_CONV_BN_FUSED', '1'))
+        self._ticket = None
         # BatchNorm-backward sums taken in the epilogue of the dgrad that last writes a layer's output gradient
         # (ops.conv_dgrad_bn_sums) instead of a separate pass over (raw, gradient).  The plan marks where that is possible
         # (graph.py::_mark_dgrad_bn_sums); the first backward times fused against separate per layer.  CY_DGRAD_BN_SUMS:
@@ -377,6 +383,15 @@ class Engine:
         if self.training and self.fused_bn:
             tbl, other = self.stats_pair[self._sp], self.stats_pair[self._sp ^ 1]
             self._sp ^= 1
+            fh = self._fwd_fused.get(idx)
+            if fh is not None:
+                res = self.view(rec['res']) if rec['res'] is not None else None
+                with ops.prof('igemm', *self._conv_work(rec)):
+                    ops.conv_bn_act_train(xv, self.wf[idx], cop, raw, self.view(rec['out']), res, rec['ks'], rec['stride'], rec['pad'],
+                                          tbl, P[bname + '.weight'], P[bname + '.bias'], P[bname + '.running_mean'],
+                                          P[bname + '.running_var'], P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, vec,
+                                          other, ops.ACT[rec['act']], self._ticket, tile=fh)
+                return
             with ops.prof('igemm', *self._conv_work(rec)):
                 ops.conv_igemm(xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=CONV_STATS, stats=tbl,
                                tile=self._fwd_tile.get(idx, 0))
@@ -495,6 +510,12 @@ class Engine:
         table, ws, _ = self._head_table
         ops.yolo_loss_multi(table, len(recs), self.N, r0['A'], r0['C'], targets, img_size, r0['ignore_thresh'], use_giou, ws,
                             self.outputs, self.plan.rows_total)
+
+    def check_grid_waits(self):
+        """Raise if a two-phase launch (ops.conv_bn_act_train) ever gave up waiting for its grid (ticket[2]): its outputs were
+        invalid.  Costs a device synchronisation: for tests, bench.py's end and whoever wants the assurance, not the step path."""
+        if self._ticket is not None and int(self._ticket[2]) != 0:
+            raise ops.CyoloError('a two-phase conv + BN launch timed out waiting for its grid (blocks not co-resident?)')
 
     # ---- backward --------------------------------------------------------------------------------
     def backward(self, grads, gout_dev, loss_scale, on_module_done=None, act_scale=None):
@@ -764,9 +785,55 @@ class Engine:
                 self._fwd_tile[idx] = self._time_hints(key, lambda h: ops.conv_bn_act_eval(
                     xv, self.wf[idx], cop, out, rec['ks'], rec['stride'], rec['pad'], vec[2], vec[3], ops.ACT[rec['act']], res,
                     tile=h), xv.C, out.C, ks=rec['ks'])
+        if self.training and self.fused_bn and self.conv_bn_fused and hasattr(ops, 'conv_bn_act_train'):
+            self._autotune_fwd_fused()
         self.stats.zero_()        # the timed launches added into the statistics table
         if self.stats_pair is not None:
             self.stats_pair[1].zero_()
+
+    def _autotune_fwd_fused(self):
+        """Which BN convs run as ONE two-phase launch (conv -> grid ticket -> BN + activation from the accumulators).  Per layer:
+        the best separate conv (already chosen) + the BN / activation pass against the fused launch over the pipelined kernel's
+        tiles that keep the grid co-resident; persisted like every other choice."""
+        self._ticket = torch.zeros(4, dtype=torch.int32, device=self.device)
+        P = self.params
+        for rec in self.plan.convs:
+            if not rec['bn']:
+                continue
+            idx, cop = rec['idx'], _pad32(rec['cout'])
+            xv, raw, out = self.view(rec['x']), self.view(rec['raw']), self.view(rec['out'])
+            res = self.view(rec['res']) if rec['res'] is not None else None
+            if xv.C % 64 or raw.C % 8:
+                continue
+            _, bname = self._names(rec)
+            vec, act = self.bnvec[idx], ops.ACT[rec['act']]
+            tbl, other = self.stats_pair
+            base = (self.dt, xv.N, xv.H, xv.W, xv.C, xv.ld, raw.C, raw.ld, out.ld, rec['ks'], rec['stride'], act, res is not None)
+
+            def fused(h):
+                if not ops.conv_bn_act_train(xv, self.wf[idx], cop, raw, out, res, rec['ks'], rec['stride'], rec['pad'], tbl,
+                                             P[bname + '.weight'], P[bname + '.bias'], None, None, None, BN_MOMENTUM, BN_EPS, vec,
+                                             other, act, self._ticket, tile=h):
+                    raise ops.CyoloError('not taken')
+            cands = [h for h in (2, 3, 4, 5, 7, 8, 9) if not (h in (3, 8) and raw.C <= 64)]
+            fhint, t_fused = self._time_hints_t(('fwd+bn',) + base, fused, xv.C, raw.C, pipe_only=True, extra=tuple(cands), hints=list(cands))
+            if fhint is None:
+                continue
+            if self.conv_bn_fused < 2:
+                sep_hint = self._fwd_tile.get(idx, 0)
+                _, t_conv = self._time_hints_t(('fwd@',) + base + (sep_hint,), lambda h: ops.conv_igemm(
+                    xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=self._stat_flags, stats=tbl, tile=sep_hint),
+                    0, 0, hints=[sep_hint])
+                _, t_bn = self._time_hints_t(('bn_act_fwd',) + base, lambda h: ops.bn_act_fwd_fused(
+                    raw, out, res, tbl, ops.conv_stats_rows(raw.M, raw.C), P[bname + '.weight'], P[bname + '.bias'], None, None, None,
+                    BN_MOMENTUM, BN_EPS, vec, other, act), 0, 0, hints=[1])
+                if os.environ.get('CY_TUNE_VERBOSE'):
+                    print('conv+bn L%d (k%d s%d %d->%d @%d): conv hint %s %.1f us + bn/act %.1f us vs fused hint %s %.1f us'
+                          % (idx, rec['ks'], rec['stride'], xv.C, raw.C, raw.H, sep_hint, 1e3 * t_conv, 1e3 * t_bn, fhint, 1e3 * t_fused), flush=True)
+                if t_fused >= t_conv + t_bn:
+                    continue
+            self._fwd_fused[idx] = fhint
+        self._ticket.zero_()
 
     def _autotune_dgrad(self):
         self._dgrad_tuned = True

@@ -420,6 +420,31 @@ def conv_bn_act_eval(g, w, wrows, out, ks, stride, pad, scale, shift, act, res=N
                tile << CONV_TILE_SHIFT, _stream())
 
 
+ERR_UNSUPPORTED = -3
+
+
+def conv_bn_act_train(g, w, wrows, raw, out, res, ks, stride, pad, bins, gamma, beta, rmean, rvar, nbt, momentum, eps, vec,
+                      zero_table, act, ticket, tile=0):
+    """Training-mode conv + BatchNorm (batch statistics) + activation (+ shortcut) in ONE two-phase launch
+    (cy_conv_bn_act_train).  -> False when this launch shape is not taken (grid not co-resident, kernel does not apply): the
+    caller keeps conv_igemm + bn_act_fwd_fused.  rmean / rvar / nbt None: running statistics left alone (tuning launches)."""
+    _require_gpu()
+    L = lib()
+    args = (_p(g), g.N, g.H, g.W, g.C, g.ld, _p(w), wrows, _p(raw), raw.H, raw.W, raw.C, raw.ld, _p(out), out.ld, _p(res),
+            res.ld if res is not None else 0, ks, stride, pad, g.dt, tile << CONV_TILE_SHIFT, _p(bins), _p(gamma), _p(beta), _p(rmean),
+            _p(rvar), _p(nbt), float(momentum), float(eps), _p(vec), _p(zero_table), zero_table.numel() if zero_table is not None else 0,
+            act, _p(ticket), _stream())
+    if L.recorder is not None:
+        L.call('cy_conv_bn_act_train', *args)        # (a recorded pass only holds launches that were accepted before)
+        return True
+    rc = L.raw('cy_conv_bn_act_train')(*args)
+    if rc == ERR_UNSUPPORTED:
+        return False
+    if rc != 0:
+        raise CyoloError('cy_conv_bn_act_train failed with status %d' % rc)
+    return True
+
+
 def wgrad_split(M, Co, Ci, ks):
     return lib().raw('cy_conv_wgrad_split')(M, Co, Ci, ks)
 

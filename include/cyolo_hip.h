@@ -26,10 +26,11 @@ typedef void* cy_stream_t; /* a hipStream_t */
 
 enum { CY_F16 = 0, CY_BF16 = 1, CY_F32 = 2 };
 enum { CY_ACT_LINEAR = 0, CY_ACT_LEAKY = 1, CY_ACT_MISH = 2 };
-enum { CY_ERR_ARG = -1 };
+enum { CY_ERR_ARG = -1, CY_ERR_UNSUPPORTED = -3 /* a valid call this kernel variant does not take: use the general path */ };
 /* cy_conv_igemm flags */
 enum { CY_CONV_STATS = 1, CY_CONV_BIAS_F32OUT = 2, CY_CONV_ACCUM = 4, CY_CONV_TRANSPOSED = 8, CY_CONV_AFFINE_ACT = 16,
-       CY_CONV_STATS_DET = 32, CY_CONV_BNBWD_SUMS = 64 /* set by cy_conv_dgrad_bn_sums only */ };
+       CY_CONV_STATS_DET = 32, CY_CONV_BNBWD_SUMS = 64 /* set by cy_conv_dgrad_bn_sums only */,
+       CY_CONV_BN_FUSED = 128 /* set by cy_conv_bn_act_train only */ };
 /* bits 8-11 of `flags`: kernel / tile hint of the call (0 = library default), see cy_conv_igemm */
 enum { CY_CONV_TILE_SHIFT = 8 };
 #define CY_CONV_TILE(h) ((h) << CY_CONV_TILE_SHIFT)
@@ -134,6 +135,25 @@ int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dt
 int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out, int OH,
                   int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags, const float* bias,
                   float* stats_part, int* stats_rows_host, cy_stream_t s);
+/* TRAINING-mode conv block in ONE kernel (reference work unit darknet2pytorch.py:247-278 under model.train(): Conv2d ->
+ * BatchNorm2d with BATCH statistics -> Mish | LeakyReLU (+ the folded [shortcut])): the fused BN + activation epilogue of
+ * the north star.  Batch statistics need every tile's sums before any tile can normalise, so the launch is two-phase:
+ * every block adds its (sum, sum of squares) into `stats_bins` (the CY_CONV_STATS table), arrives at a grid-wide ticket,
+ * stores its pre-BN tile to `raw` (kept for the backward pass) while the others arrive, then folds the bins (double, bin order:
+ * what cy_bn_act_fwd_fused does), and writes out = act((T)acc * scale + shift) (+ res) from its accumulators -- the pre-BN
+ * tensor is never read back.  Block row 0 also writes `vec` = (mean, invstd, scale, shift), the running statistics and
+ * num_batches_tracked (NULL: left alone); the grid zeroes `zero_table` (the other table of the alternating pair).
+ * Only for launches whose grid is co-resident (one round of the 8-wave kernel: blocks <= CUs x occupancy, checked here)
+ * and shapes the pipelined kernel takes (16-bit types, GC % 64 == 0, OC % 8 == 0, stride-1 or -2 forward): anything else
+ * returns CY_ERR_UNSUPPORTED and the caller keeps cy_conv_igemm + cy_bn_act_fwd_fused.  `ticket`: int32[4] zeroed once by the
+ * caller (arrivals, departures -- both back at 0 when the launch ends -- and [2] != 0 after a launch whose wait for the
+ * grid timed out: its outputs are invalid).  Results equal the two-launch path bit for bit given equal bins. */
+int cy_conv_bn_act_train(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* raw,
+                         int OH, int OW, int OC, int ldraw, void* out, int ldout, const void* res, int ldres, int ks,
+                         int stride, int pad, int dtype, int flags, float* stats_bins, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, void* num_batches_tracked,
+                         float momentum, float eps, float* vec, float* zero_table, int zero_n, int act, int32_t* ticket,
+                         cy_stream_t s);
 /* Eval-mode conv block in ONE kernel: out = act(conv(g, w) * scale[co] + shift[co]) (+ res), scale/shift being the
  * BatchNorm affine of the running statistics (cy_bn_eval_affine).  The pre-BN tensor is never written
  * (reference: the same nn.Sequential under model.eval(), evaluate.py:32-44).  flags: 0 or CY_CONV_TILE(h). */
