@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
     if (is_loader) {   // the loaders hold no results; they only keep the block's barrier count whole
         if (p.flags & CY_CONV_STATS) { __syncthreads(); __syncthreads(); }
         if (p.flags & CY_CONV_BNBWD_SUMS) __syncthreads();
-        if (p.flags & CY_CONV_BN_FUSED) { __syncthreads(); __syncthreads(); __syncthreads(); }
+        if (p.flags & CY_CONV_BN_FUSED) { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
         return;
     }
 
@@ -429,13 +429,14 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
                 // the slowest block's main loop; the iteration cap only turns a broken assumption into an error flag
                 // (ticket[2]) instead of a hung GPU
                 int spins = 0;
-                while (__hip_atomic_load(p.ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nblk_all) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (++spins > (1 << 22)) {
+                while (__hip_atomic_load(p.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblk_all) {     // (polls bypass the caches)
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1 << 23)) {
                         __hip_atomic_store(p.ticket + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE cache invalidation, after the wait
                 // the last block to leave puts the ticket back for the next launch (every block has seen it full by then)
                 if (__hip_atomic_fetch_add(p.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk_all - 1) {
                     __hip_atomic_store(p.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -444,18 +445,28 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
             }
             __syncthreads();
             float* bnv = reinterpret_cast<float*>(smem + 8 * (WROWS * ROWB));      // [2][BN]: scale, shift (behind the store tiles)
-            static_assert(8 * WROWS * ROWB + 2 * BN * 4 <= NST * STAGE, "the BN vectors fit behind the store tiles");
+            double* bsum = reinterpret_cast<double*>(bnv + 2 * BN);                  // [2][BN]: sum, sum of squares
+            static_assert(8 * WROWS * ROWB + 2 * BN * 4 + 2 * BN * 8 <= NST * STAGE, "the BN vectors fit behind the store tiles");
+            if (tid < 2 * BN) {
+                // thread (moment, channel): its CY_STAT_BINS bins requested back to back (independent loads that bypass the
+                // caches: the adds were performed at the device's coherence point), then bins in index order, double
+                // accumulation -- cy_bn_act_fwd_fused's arithmetic
+                const int mom = tid / BN, cl = tid - mom * BN, c = tn * BN + cl;
+                float v[CY_STAT_BINS];
+#pragma unroll
+                for (int b = 0; b < CY_STAT_BINS; ++b)
+                    v[b] = c < p.OC ? __hip_atomic_load(p.stats + ((size_t)b * 2 + mom) * p.OC + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                double t = 0.0;
+#pragma unroll
+                for (int b = 0; b < CY_STAT_BINS; ++b) t += (double)v[b];
+                bsum[tid] = t;
+            }
+            __syncthreads();
             if (tid < BN) {
-                // thread t owns channel tn * BN + t: bins in index order, double accumulation -- cy_bn_act_fwd_fused's arithmetic
                 const int c = tn * BN + tid;
                 float sc = 0.f, sh = 0.f;
                 if (c < p.OC) {
-                    double sm = 0.0, sq = 0.0;
-#pragma unroll
-                    for (int b = 0; b < CY_STAT_BINS; ++b) {
-                        sm += (double)__hip_atomic_load(p.stats + ((size_t)b * 2) * p.OC + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sq += (double)__hip_atomic_load(p.stats + ((size_t)b * 2 + 1) * p.OC + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    const double sm = bsum[tid], sq = bsum[BN + tid];
                     const double cnt = (double)p.M;
                     const double m = sm / cnt;
                     double var = sq / cnt - m * m;

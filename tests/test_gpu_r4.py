@@ -285,7 +285,7 @@ def test_inference_b32_608_against_reference(golden, dtype):
         d_mine = int(((out[:2, :, 6].cpu() >= thr0) ^ c32).sum())
         print('  images 0-1: rows on the other side of the confidence threshold than in float32: device f16 %d, ideal f16 storage %d (of %d candidates)'
               % (d_mine, d_ideal, int(c32.sum())))
-        assert d_mine <= 1.5 * d_ideal + 8
+        assert d_mine <= 1.5 * d_ideal + 8          # (measured: 81 vs 68 of 140)
     # (2) threshold crossings
     thr = float(g['conf_thresh'][0])
     mine = set(torch.nonzero(flat[:, 6] >= thr).reshape(-1).cpu().tolist())
@@ -471,15 +471,16 @@ def test_conv_bn_act_train_two_phase_equals_the_two_launch_path(dt, case):
         assert pad_t.numel() == 0 or float((pad_t.float() - 7.0).abs().max()) == 0.0
     cap = {2: 128, 7: 128, 3: 192, 8: 192, 4: 256, 9: 256, 5: 384}[hint]
     single_add = (M + cap - 1) // cap <= 16
-    if single_add:
-        for k in ('out', 'vec', 'rm', 'rv'):
-            assert torch.equal(a[k], b[k]), k
-    else:
-        torch.testing.assert_close(a['vec'], b['vec'], rtol=2e-5, atol=2e-6)
-        torch.testing.assert_close(a['rm'], b['rm'], rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(a['rv'], b['rv'], rtol=1e-5, atol=1e-6)
-        tol = dict(rtol=2e-2, atol=2e-2) if dt == 'bf16' else dict(rtol=3e-3, atol=3e-3)
-        torch.testing.assert_close(a['out'], b['out'], **tol)
+    # two kernels, two compilations of the same fp32 formulas (fused multiply-adds contracted differently): last-bit differences
+    # in (scale, shift) and one storage-type ulp in the output where every bin received a single add; the fp32 atomics'
+    # summation order on top where a bin received several
+    t_vec = dict(rtol=2e-6, atol=2e-7) if single_add else dict(rtol=2e-5, atol=2e-6)
+    for k in ('vec', 'rm', 'rv'):
+        torch.testing.assert_close(a[k], b[k], **t_vec)
+    ulp = 2.0 ** -7 if dt == 'bf16' else 2.0 ** -10
+    tol = dict(rtol=1.01 * ulp, atol=1e-3 * ulp) if single_add else dict(rtol=3 * ulp, atol=3 * ulp)
+    torch.testing.assert_close(a['out'], b['out'], **tol)
+    assert float((a['out'] != b['out']).float().mean()) < (0.02 if single_add else 0.2)
     # float64 reference of the block (reference darknet2pytorch.py:247-278 in train mode)
     y = F.conv2d(x.double(), w.double(), None, st, pad)
     mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
@@ -542,8 +543,11 @@ def test_model_forward_with_two_phase_convs_matches_the_separate_passes(monkeypa
     assert res['2'][4] >= 30 and res['0'][4] == 0
     assert abs(res['2'][0] - res['0'][0]) <= 5e-3 * abs(res['0'][0])
     assert got >= band - 0.05
+    # running statistics: against the run-to-run spread of the separate-pass configuration itself (deep layers see inputs that
+    # move with the atomics' order at this random init)
     for k, v in res['0'][3].items():
-        torch.testing.assert_close(res['2'][3][k], v, rtol=2e-3, atol=2e-4)
+        spread = float((res['0b'][3][k] - v).abs().max())
+        assert float((res['2'][3][k] - v).abs().max()) <= 4 * spread + 1e-5 * float(v.abs().max()) + 1e-7, k
 
 
 # ---- recorded launch lists (cy_run_plan) ----------------------------------------------------------------------------------------
@@ -593,11 +597,10 @@ def test_replayed_inference_equals_eager(monkeypatch):
     stale list."""
     outs = {}
     x = syn.bev_images(4, 608, seed=9).to(DEV)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'darknet_eval.npz'), allow_pickle=False)     # (calibrated running statistics: finite outputs)
     for mode in ('replay', 'eager'):
         monkeypatch.setenv('CY_PLAN_REPLAY', '1' if mode == 'replay' else '0')
-        model = _model('complex_yolov4.cfg', 'f16')
-        model.eval()
-        model.cpu_outputs = False
+        model = _eval_model(g, 'f16')
         model.static_eval_weights = True
         with torch.no_grad():
             a = [model(x).clone() for _ in range(4)]
@@ -611,6 +614,7 @@ def test_replayed_inference_equals_eager(monkeypatch):
         model.release_engines()
         del model
     assert outs['eager'][2] == 0 and outs['replay'][2] >= 3
+    assert bool(torch.isfinite(outs['eager'][0][0]).all())
     for i in range(4):
         assert torch.equal(outs['replay'][0][i], outs['eager'][0][0])
     for i in range(3):
