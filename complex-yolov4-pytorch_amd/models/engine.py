@@ -43,10 +43,13 @@ class Engine:
         self.det = bool(deterministic)
         self._fwd_tile, self._dgrad_tile, self._fwd_tuned, self._dgrad_tuned = {}, {}, False, False
         # conv idx -> tile hint of its two-phase conv + BN + activation launch (ops.conv_bn_act_train): the layers whose grid
-        # is one co-resident round, where the first forward timed it against conv + the separate BN / activation pass.
-        # CY_CONV_BN_FUSED: 0 never, 1 (default) timed, 2 wherever the kernel takes the launch
+        # is one co-resident round.  CY_CONV_BN_FUSED: 0 (default) never, 1 timed per layer against conv + the separate BN /
+        # activation pass, 2 wherever the kernel takes the launch.  OFF by default because it is slower on the MI355X: measured
+        # per layer (round 4, profiles/r04_two_phase_conv.txt) the grid-wide wait costs 8-18 us where the separate pass costs
+        # 6-14 us -- e.g. 256->256 3x3 @38x38: 28.9 + 10.2 us in two launches, 47.4 us fused; the timed mode picks it for none
+        # of complex_yolov4.cfg's 85 eligible layers, forcing it everywhere costs 5 % of the step
         self._fwd_fused = {}
-        self.conv_bn_fused = int(os.environ.get('CY_CONV_BN_FUSED', '1'))
+        self.conv_bn_fused = int(os.environ.get('CY_CONV_BN_FUSED', '0'))
         self._ticket = None
         # BatchNorm-backward sums taken in the epilogue of the dgrad that last writes a layer's output gradient
         # (ops.conv_dgrad_bn_sums) instead of a separate pass over (raw, gradient).  The plan marks where that is possible

@@ -408,7 +408,7 @@ def test_graph_replay_survives_head_workspace_growth_and_checkpoints_the_step_co
 FUSED_CASES = [  # N, Cin, H, Cout, ks, stride, residual, act, tile hint
     (2, 64, 19, 128, 3, 1, False, 'mish', 2), (2, 64, 19, 128, 3, 1, True, 'leaky', 7), (1, 128, 38, 64, 1, 1, False, 'linear', 4),
     (2, 64, 38, 128, 3, 2, False, 'mish', 3), (16, 256, 38, 256, 3, 1, True, 'mish', 9), (16, 512, 19, 1024, 1, 1, False, 'leaky', 3),
-    (4, 128, 76, 128, 3, 1, False, 'mish', 5), (16, 128, 76, 120, 1, 1, False, 'mish', 5),
+    (4, 128, 76, 128, 3, 1, False, 'mish', 5), (16, 128, 76, 120, 1, 1, False, 'mish', 5), (4, 64, 38, 144, 1, 1, True, 'mish', 2),
 ]
 
 
@@ -471,6 +471,19 @@ def test_conv_bn_act_train_two_phase_equals_the_two_launch_path(dt, case):
         assert pad_t.numel() == 0 or float((pad_t.float() - 7.0).abs().max()) == 0.0
     cap = {2: 128, 7: 128, 3: 192, 8: 192, 4: 256, 9: 256, 5: 384}[hint]
     single_add = (M + cap - 1) // cap <= 16
+    # float64 reference of the block (reference darknet2pytorch.py:247-278 in train mode)
+    y = F.conv2d(x.double(), w.double(), None, st, pad)
+    mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+    z = (y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5) * gamma.cpu().double().view(1, -1, 1, 1) + beta.cpu().double().view(1, -1, 1, 1)
+    ref = {'mish': z * torch.tanh(F.softplus(z)), 'leaky': F.leaky_relu(z, 0.1), 'linear': z}[actname]
+    if with_res:
+        ref = ref + res.double()
+    rtol = dict(rtol=3e-2, atol=3e-2) if dt == 'bf16' else dict(rtol=4e-3, atol=4e-3)
+    for name, r in (('two-phase', a), ('two launches', b)):
+        torch.testing.assert_close(r['out'].cpu().double(), ref, msg=lambda m, name=name: name + ' vs float64: ' + m, **rtol)
+        torch.testing.assert_close(r['vec'][0].cpu().double(), mean, rtol=1e-4, atol=1e-5)
+    unb = var * M / (M - 1)
+    torch.testing.assert_close(a['rv'].cpu().double(), 0.9 * 2.0 + 0.1 * unb, rtol=1e-4, atol=1e-5)
     # two kernels, two compilations of the same fp32 formulas (fused multiply-adds contracted differently): last-bit differences
     # in (scale, shift) and one storage-type ulp in the output where every bin received a single add; the fp32 atomics'
     # summation order on top where a bin received several
@@ -481,18 +494,6 @@ def test_conv_bn_act_train_two_phase_equals_the_two_launch_path(dt, case):
     tol = dict(rtol=1.01 * ulp, atol=1e-3 * ulp) if single_add else dict(rtol=3 * ulp, atol=3 * ulp)
     torch.testing.assert_close(a['out'], b['out'], **tol)
     assert float((a['out'] != b['out']).float().mean()) < (0.02 if single_add else 0.2)
-    # float64 reference of the block (reference darknet2pytorch.py:247-278 in train mode)
-    y = F.conv2d(x.double(), w.double(), None, st, pad)
-    mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
-    z = (y - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5) * gamma.cpu().double().view(1, -1, 1, 1) + beta.cpu().double().view(1, -1, 1, 1)
-    ref = {'mish': z * torch.tanh(F.softplus(z)), 'leaky': F.leaky_relu(z, 0.1), 'linear': z}[actname]
-    if with_res:
-        ref = ref + res.double()
-    tol = dict(rtol=3e-2, atol=3e-2) if dt == 'bf16' else dict(rtol=4e-3, atol=4e-3)
-    torch.testing.assert_close(a['out'].cpu().double(), ref, **tol)
-    torch.testing.assert_close(a['vec'][0].cpu().double(), mean, rtol=1e-4, atol=1e-5)
-    unb = var * M / (M - 1)
-    torch.testing.assert_close(a['rv'].cpu().double(), 0.9 * 2.0 + 0.1 * unb, rtol=1e-4, atol=1e-5)
 
 
 def test_conv_bn_act_train_refuses_a_grid_of_more_than_one_round():
