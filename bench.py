@@ -88,7 +88,7 @@ def kernel_sources_sha():
     return tune.sources_sha()
 
 
-PMC_FILE = 'profiles/r03_pmc_hbm_traffic.json'
+PMC_FILE = 'profiles/r04_pmc_hbm_traffic.json'
 
 
 def pmc_traffic(kernel, a):
@@ -571,6 +571,9 @@ def main():
         dist.barrier()
 
     fused_layers = max((len(e._sums_fused) for e in model._engines.values()), default=0)
+    replayed = sum(getattr(e, 'replayed', 0) for e in model._engines.values())
+    for e in model._engines.values():
+        e.check_grid_waits()
     sf_all = step_flops(model)         # per-GPU algorithmic FLOPs of one step (weak scaling: the same on every rank)
     if rank == 0:
         cpu = None
@@ -601,7 +604,9 @@ def main():
             'config': {'workload': 'complex_yolov4.cfg train step (%sfwd + rotated-GIoU loss + bwd + Adam), batch %d per GPU, %dx%dx3 synthetic BEV, %d targets/image'
                                    % ('device mosaic of four maps per sample + ' if cfg.get('mosaic') else '', a.batch, a.size, a.size, 24 if cfg.get('mosaic') else 6),
                        'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4),
-                       'deterministic': bool(a.deterministic), 'issue': graph_note,
+                       'deterministic': bool(a.deterministic),
+                       'issue': graph_note if graphed is not None or not replayed else
+                       'recorded launch lists replayed from C (cy_run_plan): every kernel still launches eagerly, %d passes replayed' % replayed,
                        'dgrad_bn_sums_layers': fused_layers,
                        'yolo_outputs': 'stay on the device in training (the reference copies 14.6 MB to the host every step, '
                                        'darknet2pytorch.py:228, and train.py discards them)'},
