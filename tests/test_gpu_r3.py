@@ -19,10 +19,15 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 
 # Stated bands of the 16-bit storage modes on BASELINE configs[1]'s own shape, against the reference's fp32 CPU step
 # (tests/golden/darknet_big.npz).  Measured values are printed by the test and quoted in DESIGN.md section 4.
+# (No element-wise gradient bound HERE: at this random init the net amplifies a 1e-7 perturbation to 4e-2 -- the oracle's own
+# float32 and float64 runs differ by that, profiles/r04_oracle_f64_vs_f32.txt -- so 16-bit gradients are uncorrelated with the
+# reference's element by element; round 3 "bounded" them at 300 %, which bounded nothing.  The element-wise evidence for the
+# 16-bit modes is on a CONDITIONED net, with controls: tests/test_gpu_r4.py::test_conditioned_net_16bit_step_agrees_with_fp32 and
+# ::test_16bit_step_matches_ideal_16bit_storage.)
 BANDS = {
-    #        loss rel, prob median, prob max, grad-norm ratio median window, element-wise gradient-head median
-    'f16': dict(loss=1e-2, pmed=4e-2, pmax=0.5, gn=(0.9, 1.1), ghead=3.0),
-    'bf16': dict(loss=6e-2, pmed=0.15, pmax=0.9, gn=(0.8, 1.25), ghead=3.0),
+    #        loss rel, prob median, prob max, grad-norm ratio median window
+    'f16': dict(loss=1e-2, pmed=4e-2, pmax=0.5, gn=(0.9, 1.1)),
+    'bf16': dict(loss=6e-2, pmed=0.15, pmax=0.9, gn=(0.8, 1.25)),
 }
 
 
@@ -56,7 +61,6 @@ def test_v4_16bit_band_at_benchmark_shape(golden, dtype):
     assert rel < b['loss']
     assert np.median(dprob) < b['pmed'] and dprob.max() < b['pmax']
     assert b['gn'][0] < np.median(ratio) < b['gn'][1]
-    assert np.median(err) < b['ghead']
 
 
 def _worker(job, tmp_path, name, *args, timeout=600, env_extra=None):
