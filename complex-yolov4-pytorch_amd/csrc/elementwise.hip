@@ -984,9 +984,13 @@ extern "C" int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const voi
 
 // channel group / pixels per block of the fused kernels: CG <= 128 channels with 256 / (CG / ch) rows per pass
 static inline int fused_cg(int C, int ch) {
-    int cg = C < 128 ? C : 128;
-    while (C % cg || 256 % (cg / ch)) cg /= 2;
-    return cg;
+    // the largest CG = ch * 2^j <= 128 that divides C (2^j chunks per pixel row divide the block's 256 threads).  C % ch == 0 is
+    // the callers' precondition, so CG = ch always qualifies.  (Round 4: the halving search this replaces walked 120 -> 60 -> 30
+    // -> 15 for C = 120 and launched with CG = 15, not a multiple of the chunk: wrong outputs for channel counts that are not
+    // 2^j * (a divisor of 128) -- none in the reference's cfgs, found by the ragged-channel case of the two-phase conv test.)
+    for (int k = 128 / ch; k >= 1; k >>= 1)
+        if (k * ch <= C && C % (k * ch) == 0) return k * ch;
+    return 0;
 }
 
 extern "C" int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,

@@ -157,9 +157,7 @@ class Engine:
         self.fwd_serial = 0
         self._reduce_groups = None
         use_side = training and getattr(device, 'type', str(device)) == 'cuda' and os.environ.get('CY_WGRAD_SIDE_STREAM', '1') != '0'
-        # (CY_SIDE_PRIORITY: stream priority of the weight-gradient stream; a LARGER number is a LOWER priority, out-of-range
-        # values are clamped by the runtime.  Experiment switch)
-        self.side = torch.cuda.Stream(device=device, priority=int(os.environ.get('CY_SIDE_PRIORITY', '0'))) if use_side else None
+        self.side = torch.cuda.Stream(device=device) if use_side else None
         self.dummy = torch.zeros(16, **f32)
         # pools
         self.argmax, self.pool_scratch = {}, None
