@@ -249,11 +249,18 @@ class Engine:
                 if rec_on:
                     prog = ops.stop_recording()
                     prog.sp_after = self._sp
-                    self._fwd_progs[key] = prog
+                    self._remember(self._fwd_progs, key, prog)
         if self._heads_on_side:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
             self._heads_on_side = False
         return self.outputs
+
+    MAX_PROGRAMS = 64        # recorded launch lists kept per direction (one per target-row count seen: ~150 KB of host memory each)
+
+    def _remember(self, table, key, prog):
+        if len(table) >= self.MAX_PROGRAMS:      # (KITTI batches differ in their number of boxes: oldest recordings go first)
+            table.pop(next(iter(table)))
+        table[key] = prog
 
     def _own_targets(self, targets):
         """The caller's target rows copied into an engine-owned buffer (a recorded launch list needs them at a fixed address);
@@ -584,7 +591,7 @@ class Engine:
         if can:
             prog = ops.stop_recording()
             prog.bp_after = self._bp
-            self._bwd_progs[key] = prog
+            self._remember(self._bwd_progs, key, prog)
 
     def _flush_group(self, g):
         """Fold the split-K slabs of one group of convs into the flat gradient and announce its modules as final.  With
