@@ -693,14 +693,16 @@ def test_maxpooldark_kernels(dt, k, stride, H):
     torch.testing.assert_close(dxv.to_nchw().cpu(), 1 + xr.grad.float(), **tol)
 
 
-def test_v3_tiny_train_step_on_device():
-    """complex_yolov3_tiny.cfg (MaxPoolDark between its last two backbone convs) -- refused by round 3's plan -- one fp32
-    parity-mode train step against the oracle: loss, outputs, parameter gradients."""
+@pytest.mark.parametrize('cfgname', ['complex_yolov3_tiny.cfg', 'complex_yolov3.cfg'])
+def test_v3_tiny_train_step_on_device(cfgname):
+    """The reference's other two cfgs: complex_yolov3_tiny.cfg (MaxPoolDark between its last two backbone convs; refused by
+    round 3's plan; a 16-channel first layer) and complex_yolov3.cfg (Darknet-53 + FPN, leaky throughout) -- one fp32 parity-mode
+    train step against the oracle: loss, outputs, parameter gradients (leaky kinks: most tensors tight, none wrong)."""
     from complex_yolov4_pytorch_amd.models.darknet_utils import parse_cfg
     from oracle import darknet_ref
     from tests.util import grad_rel_errors
-    cfg = os.path.join(ROOT, 'complex-yolov4-pytorch_amd', 'config', 'cfg', 'complex_yolov3_tiny.cfg')
-    model = _model('complex_yolov3_tiny.cfg', 'f32', deterministic=True)
+    cfg = os.path.join(ROOT, 'complex-yolov4-pytorch_amd', 'config', 'cfg', cfgname)
+    model = _model(cfgname, 'f32', deterministic=True)
     model.train()
     x, tg = syn.bev_images(2, 224, seed=7, sparsity=0.5), syn.targets(2, 4, 224, seed=7)
     loss, out = model(x.to(DEV), tg.to(DEV))
@@ -713,6 +715,10 @@ def test_v3_tiny_train_step_on_device():
     np.testing.assert_allclose(float(loss.detach()), float(l_ref.detach().sum()), rtol=1e-4)
     np.testing.assert_allclose(out.cpu().numpy(), o_ref.detach().numpy(), rtol=2e-3, atol=2e-3)
     errs = grad_rel_errors([(n, p.grad.cpu()) for n, p in model.named_parameters()], {k: v.grad for k, v in params.items()})
-    print('v3-tiny fp32 step vs oracle: loss %.5f / %.5f, gradient rel err median %.2e max %.2e'
-          % (float(loss.detach()), float(l_ref.detach().sum()), float(np.median(list(errs.values()))), max(errs.values())))
-    assert max(errs.values()) < 5e-2 and np.median(list(errs.values())) < 2e-3
+    v = np.asarray(list(errs.values()))
+    print('%s fp32 step vs oracle: loss %.5f / %.5f, gradient rel err median %.2e 90th pct %.2e max %.2e'
+          % (cfgname, float(loss.detach()), float(l_ref.detach().sum()), float(np.median(v)), float(np.percentile(v, 90)), float(v.max())))
+    if 'tiny' in cfgname:
+        assert v.max() < 5e-2 and np.median(v) < 2e-3
+    else:       # 75 leaky layers at batch 2: a pre-activation within round-off of zero flips its slope in one of the two evaluation orders (tests/util.py)
+        assert v.max() < 1.0 and np.median(v) < 2e-2 and (v < 5e-2).mean() > 0.7
