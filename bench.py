@@ -281,12 +281,13 @@ def _free_port():
     return p
 
 
-def self_launch(n, argv, sim=False):
+def self_launch(n, argv, script=None, need_gpus=True):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU (what the reference's
     mp.spawn does, src/train.py:46-52), through torch.distributed.run on 127.0.0.1; rank 0's JSON line is the children's
-    stdout, passed through.  -> exit status."""
+    stdout, passed through.  -> exit status.  (`script` / `need_gpus`: tests/test_bench_launch.py starts CPU ranks of
+    tests/bench_sim.py through the same function.)"""
     import subprocess
-    if not sim:
+    if need_gpus:
         have = torch.cuda.device_count()
         if have < n:
             sys.stderr.write('bench.py: --gpus %d needs %d GPUs on this node, %d visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)\n'
@@ -296,61 +297,8 @@ def self_launch(n, argv, sim=False):
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cores(256) // n)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+           '--master-port', str(_free_port()), os.path.abspath(script or __file__)] + list(argv)
     return subprocess.run(cmd, env=env).returncode
-
-
-def sim_main(a, rank, world):
-    """tests/test_bench_launch.py: the rank plumbing of this script (launch, barrier, max-over-ranks timing, per-rank line) on CPU
-    ranks over gloo, operator layer = tests/opsim.py, mini cfg.  Nothing here is a measurement."""
-    from tests import opsim
-    from tests.util import mini_cfg_path
-
-    class _MP:
-        def setattr(self, o, n, v):
-            setattr(o, n, v)
-    opsim.install(_MP())
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29512')
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.manual_seed(0)
-    torch.set_num_threads(2)
-    model = Darknet(mini_cfg_path(), use_giou_loss=True, dtype='f32')
-    model.train()
-    net = RcclDataParallel(model, bucket_bytes=64 << 10)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    x, tg = syn.bev_images(2, 64, seed=rank, sparsity=0.5), syn.targets(2, 3, 64, seed=rank)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss, _ = net(x, tg)
-        loss.backward()
-        opt.step()
-        return loss
-
-    for _ in range(a.warmup):
-        step()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    dist.barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    every = [torch.zeros_like(elapsed) for _ in range(world)]
-    dist.all_gather(every, elapsed)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    w0 = next(model.parameters()).detach().double().sum().reshape(1)
-    ws = [torch.zeros_like(w0) for _ in range(world)]
-    dist.all_gather(ws, w0)
-    dist.destroy_process_group()
-    if rank == 0:
-        emit({'metric': 'SIMULATED ranks (CPU, gloo, mini cfg): launch plumbing only', 'value': round(world * 2 * a.steps / float(elapsed), 3),
-              'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * float(elapsed) / a.steps, 3),
-              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-              'config': {'workload': 'simulated', 'global_batch': 2 * world, 'parallelism': 'dp%d' % world,
-                         'loss_final': round(float(loss.detach().reshape(-1)[0]), 4)},
-              'per_rank_ms_per_step': [round(1e3 * float(t) / a.steps, 3) for t in every],
-              'params_equal_across_ranks': bool(all(float(w) == float(ws[0]) for w in ws))})
 
 
 def main():
@@ -369,21 +317,18 @@ def main():
     ap.add_argument('--graph', type=int, default=0, help='1: the step as one captured hipGraph (graphed.GraphedTrainStep); default 0 = '
                     'eager launches: on ROCm 7.2 the replay of the 660-node, two-stream graph takes 33.1 ms against 19.2 ms eager '
                     '(DESIGN.md section 5), so the measured configuration is the eager one')
-    ap.add_argument('--sim', action='store_true', help=argparse.SUPPRESS)     # tests only: CPU ranks over gloo on tests/opsim.py
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     a.batch = a.batch or cfg['batch']
     a.size = a.size or cfg['size']
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        sys.exit(self_launch(a.gpus, sys.argv[1:], sim=a.sim))
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if a.gpus != world and (a.gpus > 1 or world > 1):
         sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks (use --nproc-per-node %d)' % (a.gpus, world, a.gpus))
-    if a.sim:
-        return sim_main(a, rank, world)
     if torch.cuda.device_count() <= local:
         sys.exit('bench.py: rank %d needs GPU %d but this node exposes %d device(s)' % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
