@@ -56,6 +56,15 @@ class _OptCfg:
     optimizer_type, lr, momentum, weight_decay = 'adam', 1e-3, 0.949, 5e-4     # reference train_config.py:82-94
 
 
+_T0 = time.time()
+
+
+def stage(msg):
+    """Progress marker on stderr (never stdout: that carries the ONE JSON line): where a run was when it died."""
+    sys.stderr.write('[bench %7.2fs] %s\n' % (time.time() - _T0, msg))
+    sys.stderr.flush()
+
+
 def emit(line):
     """The ONE JSON line, last on stdout: RCCL writes its version banner through C stdio, which would otherwise be flushed
     after Python's buffer at exit -- flush both first."""
@@ -256,10 +265,12 @@ def batch_source(dev, batch, size, mosaic, seed=0):
 def measure_other(config, dtype, steps, warmup):
     """One of the other configurations, measured by this same script in a fresh process (its ONE JSON line, reduced)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--config', config, '--dtype', dtype, '--steps', str(steps), '--warmup', str(warmup),
-           '--no-extra', '--no-cpu-baseline', '--no-roofline']
+    cmd = [sys.executable, os.path.abspath(__file__), '--worker', '--config', config, '--dtype', dtype, '--steps', str(steps),
+           '--warmup', str(warmup), '--no-extra', '--no-cpu-baseline', '--no-roofline']
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        if r.returncode != 0:
+            return dict(error='%s: worker exit status %d' % (config, r.returncode), stderr_tail=r.stderr[-400:])
         d = json.loads(r.stdout.strip().splitlines()[-1])
         out = dict(metric=d['metric'], value=d['value'], unit=d['unit'], ms_per_step=d['ms_per_step'], steps=d['steps'], dtype=d['dtype'],
                    workload=d['config']['workload'], loss_final=d['config'].get('loss_final'), process='fresh')
@@ -301,7 +312,7 @@ def self_launch(n, argv, script=None, need_gpus=True):
     return subprocess.run(cmd, env=env).returncode
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -317,13 +328,34 @@ def main():
     ap.add_argument('--graph', type=int, default=0, help='1: the step as one captured hipGraph (graphed.GraphedTrainStep); default 0 = '
                     'eager launches: on ROCm 7.2 the replay of the 660-node, two-stream graph takes 33.1 ms against 19.2 ms eager '
                     '(DESIGN.md section 5), so the measured configuration is the eager one')
-    a = ap.parse_args()
+    ap.add_argument('--worker', action='store_true', help='internal: the measuring process (owns the GPU context); the plain command '
+                    'is a supervisor that starts it, retries it once after a GPU fault and assembles the line')
+    ap.add_argument('--map-file', default=None, help='internal: where the worker leaves its device buffer map for the supervisor')
+    a = ap.parse_args(argv)
     cfg = CONFIGS[a.config]
     a.batch = a.batch or cfg['batch']
     a.size = a.size or cfg['size']
+    return a
 
+
+def main():
+    a = parse_args()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if a.gpus != world and (a.gpus > 1 or world > 1):
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks (use --nproc-per-node %d)' % (a.gpus, world, a.gpus))
+    if a.worker:
+        return worker(a)
+    sys.exit(supervise(a, sys.argv[1:]))
+
+
+def worker(a):
+    """The measurement itself, in a process of its own: everything that touches the GPU.  Prints the line of ITS part (the
+    headline configuration with `roofline`); the supervisor adds `other_configs` and `cpu_baseline`."""
+    import faulthandler
+    faulthandler.enable(all_threads=False)      # a GPU fault ends in abort(): leave the Python stack of the main thread on stderr
+    cfg = CONFIGS[a.config]
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -364,6 +396,7 @@ def main():
             emit(line)
         return
 
+    stage('device up, building the model')
     torch.manual_seed(0)
     model = Darknet(CFG, use_giou_loss=True, dtype=a.dtype, deterministic=a.deterministic).to(dev)
     model.train()
@@ -403,16 +436,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
+        stage('warm-up step %d' % i)
         step()
     if isinstance(net, RcclDataParallel):
         net.exposed_events = []      # (before, after) the compute stream's wait for the all-reduce stream, one pair per step
     sync()
+    if a.map_file:
+        write_buffer_map(a.map_file, model, opt)
+    stage('timed region: %d steps' % a.steps)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     sync()
     mine = time.perf_counter() - t0
+    stage('timed region done: %.3f ms per step' % (1e3 * mine / a.steps))
     elapsed = torch.tensor([mine], device=dev, dtype=torch.float64)
     per_rank_ms, exposed_ms = None, None
     if isinstance(net, RcclDataParallel):
@@ -431,6 +469,10 @@ def main():
         exposed_ms = round(float(exposed), 3)
     elapsed = float(elapsed)
     final_loss = float(loss.detach().reshape(-1)[0])
+    if rank == 0:
+        # the headline is safe from here on: the supervisor falls back to this line if a later leg of the worker dies
+        emit({'partial': True, 'value': round(world * a.batch * a.steps / elapsed, 3), 'ms_per_step': round(1e3 * elapsed / a.steps, 3),
+              'loss_final': round(final_loss, 4), 'per_rank_ms_per_step': per_rank_ms, 'allreduce_exposed_ms_per_step': exposed_ms})
 
     roofline = None
     summ, by_bound = {}, None
@@ -438,6 +480,7 @@ def main():
         # exclusive kernel durations: the probe steps issue the weight-gradient kernels on the main stream (in the timed
         # region they overlap the dgrad/BN kernels from a side stream, which stretches every kernel's own duration).
         # EVERY rank runs the probe steps (a step contains the gradient all-reduce); only rank 0 brackets its launches.
+        stage('roofline probe steps (single stream, bracketed launches)')
         sides = [(e, e.side) for e in model._engines.values()]
         for e, _ in sides:
             e.side = None
@@ -521,25 +564,6 @@ def main():
         e.check_grid_waits()
     sf_all = step_flops(model)         # per-GPU algorithmic FLOPs of one step (weak scaling: the same on every rank)
     if rank == 0:
-        cpu = None
-        others = None
-        if world == 1 and a.config == 'train608' and not a.no_extra:
-            # free this configuration's 17 GB of storages, then measure configs[3], configs[4], the bf16 mode and configs[2]'s
-            # per-GPU work briefly -- each in a FRESH PROCESS.  In one process the later configurations ran on whatever the
-            # earlier ones left behind: tools/order_probe.py (profiles/r03_order_probe.txt) shows train1216 at 234 images/s
-            # as the first 54 GB allocation of a process, 200 after a 17 GB configuration was allocated and freed in between,
-            # 236 again on the next try, with train608 and the clocks unchanged throughout -- the state of the device's
-            # memory mappings after a free / re-allocate, not the kernels (round 2's "15 % slower inside the default run").
-            model.release_engines()
-            del opt
-            torch.cuda.empty_cache()
-            others = {'infer32': measure_other('infer32', a.dtype, 8, 3),
-                      'train1024': measure_other('train1024', a.dtype, 5, 2)}
-            if a.dtype == 'f16':
-                others['train608_bf16'] = measure_other('train608', 'bf16', 6, 3)
-            others['train1216_mosaic'] = measure_other('train1216', a.dtype, 4, 3)
-        if not a.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(2, a.size)
         imgs = world * a.batch * a.steps
         line = {
             'metric': 'BEV images/s (%dx%d) train step' % (a.size, a.size), 'value': round(imgs / elapsed, 3), 'unit': 'images/s',
@@ -555,7 +579,7 @@ def main():
                        'dgrad_bn_sums_layers': fused_layers,
                        'yolo_outputs': 'stay on the device in training (the reference copies 14.6 MB to the host every step, '
                                        'darknet2pytorch.py:228, and train.py discards them)'},
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'cpu_baseline': None,
             'step': dict(step_gflop=round(sf_all / 1e9, 1), step_tflops=round(sf_all / (elapsed / a.steps) / 1e12, 1),
                          step_frac=round(sf_all / (elapsed / a.steps) / (MFMA_PEAK_TFLOPS[a.dtype] * 1e12), 4)),
         }
@@ -563,12 +587,174 @@ def main():
             line['per_rank_ms_per_step'] = per_rank_ms
         if exposed_ms is not None:
             line['allreduce_exposed_ms_per_step'] = exposed_ms      # 0 = fully hidden behind backward
-        if others:
-            line['other_configs'] = others
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
         emit(line)
+
+
+def write_buffer_map(path, model, opt):
+    """Every device buffer of the step by name -> `path` (JSON): the supervisor maps the address of a GPU memory-access fault
+    onto it.  Host-side bookkeeping only (data_ptr / sizes / the caching allocator's segment list)."""
+    rows = []
+    try:
+        for key, e in model._engines.items():
+            rows += [('engine%r.%s' % (key[:3], n), p_, b) for n, p_, b in e.buffer_map()]
+        for n, t in list(model.named_parameters()) + list(model.named_buffers()):
+            rows.append(('param ' + n, t.data_ptr(), t.numel() * t.element_size()))
+        if model.flat_grad is not None:
+            rows.append(('flat_grad', model.flat_grad.data_ptr(), model.flat_grad.numel() * 4))
+        for st in getattr(opt, 'state', {}).values():
+            for k, v in st.items():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    rows.append(('optimizer.' + k, v.data_ptr(), v.numel() * v.element_size()))
+        segs = [(sg['address'], sg['total_size']) for sg in torch.cuda.memory_snapshot()]
+        with open(path, 'w') as f:
+            json.dump({'buffers': rows, 'segments': segs}, f)
+    except Exception as e:      # noqa: BLE001 -- diagnostics must never cost the measurement
+        stage('buffer map not written: %r' % (e,))
+
+
+def diagnose_fault(stderr_text, map_file):
+    """What the worker's stderr and its buffer map say about a GPU fault: the address, the buffer it falls into (or the nearest
+    ones), the last stage marker and the main thread's Python stack (faulthandler)."""
+    import re
+    d = {}
+    m = re.search(r'Memory access fault by GPU node-(\d+).*?on address (0x[0-9a-fA-F]+)\. Reason: ([^\n]*)', stderr_text)
+    stages = re.findall(r'\[bench +[0-9.]+s\] ([^\n]*)', stderr_text)
+    if stages:
+        d['last_stage'] = stages[-1]
+    fh = stderr_text.find('Current thread')
+    if fh < 0:
+        fh = stderr_text.find('Fatal Python error')
+    if fh >= 0:
+        d['python_stack'] = [ln.strip() for ln in stderr_text[fh:].splitlines()[1:9]]
+    if not m:
+        d['stderr_tail'] = stderr_text[-600:]
+        return d
+    addr = int(m.group(2), 16)
+    d.update(address=m.group(2), reason=m.group(3).strip())
+    try:
+        with open(map_file) as f:
+            doc = json.load(f)
+        inside = [(n, p_, b) for n, p_, b in doc['buffers'] if p_ <= addr < p_ + b]
+        if inside:
+            n, p_, b = min(inside, key=lambda r: r[2])
+            d['buffer'] = '%s + %d of %d bytes' % (n, addr - p_, b)
+        else:
+            below = max([r for r in doc['buffers'] if r[1] + r[2] <= addr], key=lambda r: r[1] + r[2], default=None)
+            above = min([r for r in doc['buffers'] if r[1] > addr], key=lambda r: r[1], default=None)
+            d['buffer'] = None
+            if below:
+                d['nearest_below'] = '%s ends %d bytes before the address' % (below[0], addr - below[1] - below[2])
+            if above:
+                d['nearest_above'] = '%s starts %d bytes after the address' % (above[0], above[1] - addr)
+        d['in_allocator_segment'] = any(a0 <= addr < a0 + sz for a0, sz in doc['segments'])
+    except (OSError, ValueError, KeyError) as e:
+        d['map'] = 'unavailable (%r): the fault came before the end of the warm-up' % (e,)
+    return d
+
+
+def run_worker(argv, map_file, timeout=1500):
+    """One worker process of this script -> (exit status, last complete JSON line or None, last partial line or None, stderr).
+    stderr is forwarded line by line (stage markers stay visible while the run is alive) and kept for the diagnosis."""
+    import subprocess
+    import threading
+    cmd = [sys.executable, os.path.abspath(__file__), '--worker', '--map-file', map_file] + [x for x in argv if x != '--worker']
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    err = []
+
+    def pump():
+        for ln in p.stderr:
+            err.append(ln)
+            sys.stderr.write(ln)
+            sys.stderr.flush()
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    try:
+        out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out, _ = p.communicate()
+        err.append('bench.py supervisor: worker killed after %d s\n' % timeout)
+    t.join(timeout=5)
+    full = part = None
+    for ln in (out or '').splitlines():
+        if ln.startswith('{'):
+            try:
+                d = json.loads(ln)
+            except ValueError:
+                continue
+            if d.get('partial'):
+                part = d
+            else:
+                full = d
+    return p.returncode, full, part, ''.join(err)
+
+
+def supervise(a, argv):
+    """What `python bench.py ...` is: a process WITHOUT a GPU context that starts the measuring worker, and -- because a GPU
+    memory-access fault kills the process it happens in (round 4's driver run ended that way, BENCH_r04.json, with nothing on
+    stdout) -- survives it: the worker is retried once (single GPU), every fault is reported on the line (`fault_retries`,
+    `faults` with the address mapped onto the worker's buffers), and rank 0 ALWAYS prints one JSON line, with `error` if no
+    attempt produced a measurement.  Under a launcher every rank is such a pair."""
+    import tempfile
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    map_file = os.path.join(tempfile.gettempdir(), 'cy_bench_map_%d.json' % os.getpid())
+    faults, full, part, tries = [], None, None, 0
+    attempts = 2 if world == 1 else 1       # (a retry under a launcher would need every rank to agree on it)
+    for attempt in range(attempts):
+        tries += 1
+        rc, f2, p2, err = run_worker(argv, map_file)
+        part = p2 or part
+        full = f2 if f2 is not None else full      # (a worker that printed its line and died at teardown still measured)
+        if rc != 0 or (rank == 0 and f2 is None):
+            d = diagnose_fault(err, map_file)
+            d.update(attempt=attempt, exit_status=rc)
+            faults.append(d)
+            stage('worker attempt %d ended with status %s: %s' % (attempt, rc, json.dumps(d)[:600]))
+        if full is not None or (rank != 0 and rc == 0):
+            break
+    try:
+        os.remove(map_file)
+    except OSError:
+        pass
+    if rank != 0:
+        return 0 if not faults or full is not None else 1
+    cfg = CONFIGS[a.config]
+    if full is None:
+        line = {'metric': 'BEV images/s (%dx%d) %s' % (a.size, a.size, 'train step' if cfg['kind'] == 'train' else 'inference + rotated NMS'),
+                'value': part['value'] if part else None, 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+                'ms_per_step': part['ms_per_step'] if part else None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': a.dtype, 'data': 'synthetic', 'config': {'workload': a.config, 'global_batch': world * a.batch},
+                'roofline': None, 'cpu_baseline': None,
+                'error': 'the measuring worker died in every attempt' + ('' if part is None else ' AFTER the timed region: value / ms_per_step are '
+                         'the completed timed region of the last attempt, the roofline leg is missing')}
+    else:
+        line = full
+    line['fault_retries'] = tries - 1
+    if faults:
+        line['faults'] = faults
+    if world == 1 and a.config == 'train608' and cfg['kind'] == 'train':
+        if not a.no_extra:
+            # configs[3], configs[4], the bf16 mode and configs[2]'s per-GPU work, briefly -- each in a FRESH PROCESS (one process
+            # per configuration: tools/order_probe.py, profiles/r03_order_probe.txt, shows train1216 at 234 images/s as the first
+            # 54 GB allocation of a process and 200 after a 17 GB configuration was allocated and freed before it)
+            stage('other configurations in fresh processes')
+            others = {'infer32': measure_other('infer32', a.dtype, 8, 3),
+                      'train1024': measure_other('train1024', a.dtype, 5, 2)}
+            if a.dtype == 'f16':
+                others['train608_bf16'] = measure_other('train608', 'bf16', 6, 3)
+            others['train1216_mosaic'] = measure_other('train1216', a.dtype, 4, 3)
+            line['other_configs'] = others
+        if not a.no_cpu_baseline:
+            stage('cpu_baseline (oracle on the host cores)')
+            try:
+                line['cpu_baseline'] = cpu_baseline(2, a.size)
+            except Exception as e:      # noqa: BLE001
+                line['cpu_baseline'] = dict(error=repr(e))
+    emit(line)
+    return 0 if full is not None else 1
 
 
 if __name__ == '__main__':

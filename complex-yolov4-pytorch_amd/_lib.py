@@ -17,6 +17,9 @@ _SCALARS = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_fl
             'int32_t': ctypes.c_int32, 'uint32_t': ctypes.c_uint32}
 
 
+_TRACE_SYNC = os.environ.get('CY_TRACE_SYNC') == '1'      # fault hunting only (see _Lib._call_traced)
+
+
 class CyoloError(RuntimeError):
     pass
 
@@ -136,9 +139,24 @@ class _Lib:
         """Call an int-returning entry point; raise on a non-zero status."""
         if self.recorder is not None:
             self.recorder.call(name, args)
+        if _TRACE_SYNC:
+            return self._call_traced(name, args)
         rc = getattr(self._dll, name)(*args)
         if rc != 0:
             raise CyoloError('%s failed with status %d' % (name, rc))
+        return rc
+
+    def _call_traced(self, name, args):
+        """CY_TRACE_SYNC=1 (fault hunting): name and arguments of every call go to stderr BEFORE it is issued and the device is
+        synchronised after it, so that a GPU memory-access fault is attributed to the last line printed."""
+        import sys
+        sys.stderr.write('cy> %s %s\n' % (name, ' '.join(
+            ('%#x' % (a.value or 0)) if isinstance(a, ctypes.c_void_p) else ('host[]' if isinstance(a, ctypes.Array) else repr(a)) for a in args)))
+        sys.stderr.flush()
+        rc = getattr(self._dll, name)(*args)
+        if rc != 0:
+            raise CyoloError('%s failed with status %d' % (name, rc))
+        torch.cuda.synchronize()
         return rc
 
 

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from .. import ops
 from .darknet_utils import load_conv, load_conv_bn, parse_cfg, print_cfg, save_conv, save_conv_bn
-from .engine import Engine
+from .engine import Arena, Engine
 from .graph import Plan, lower_blocks
 from .yolo_layer import YoloLayer
 
@@ -241,7 +241,9 @@ class Darknet(nn.Module):
             self._plist = named
         if self._grad_flat is None or self._grad_flat.device != named[0][1].device:
             total = sum(p.numel() for _, p in named)
-            self._grad_flat = torch.zeros(total, dtype=torch.float32, device=named[0][1].device)
+            dev = named[0][1].device
+            self._grad_arena = Arena(dev, Engine.GUARD_BYTES if dev.type == 'cuda' else 0)      # (red zones: tests/test_gpu_redzone.py)
+            self._grad_flat = self._grad_arena.new('flat_grad', total, torch.float32, zero=True)
             self._grad_views, off = {}, 0
             for name, p in named:
                 self._grad_views[name] = self._grad_flat[off:off + p.numel()].view_as(p)

@@ -34,9 +34,50 @@ _CONV_TUNE_MEMO = {}      # (kind, shape key) -> best kernel / tile hint, shared
 _DET_TIMING = os.environ.get('CY_TUNE_DET_TIMING') == '1'
 
 
+class Arena:
+    """Allocates an engine's device buffers.  With ``guard`` > 0 (tests/test_gpu_redzone.py; CY_GUARD_BYTES) every buffer sits
+    between two bands of ``guard`` bytes of 0xFF -- NaN in every floating-point type the kernels read -- inside its own
+    allocation: ``violations()`` names the buffers whose bands a kernel wrote into, and an over-READ drags NaNs into results
+    that the test compares bit for bit with an unguarded run."""
+
+    def __init__(self, device, guard=0):
+        self.device, self.guard, self.blocks = device, int(guard), []
+
+    def new(self, name, shape, dtype, zero=False):
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        if not self.guard:
+            return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        g = self.guard
+        raw = torch.full((g + nbytes + (-nbytes % 256) + g,), 0xFF, dtype=torch.uint8, device=self.device)
+        mid = raw[g:g + nbytes].view(dtype).view(shape)
+        if zero:
+            mid.zero_()
+        self.blocks.append((name, raw, nbytes))
+        return mid
+
+    def violations(self):
+        """[(buffer name, 'below' | 'above', first damaged byte's distance from the buffer)] -- empty when every band is intact."""
+        bad, g = [], self.guard
+        for name, raw, nbytes in self.blocks:
+            lo, hi = raw[:g] != 0xFF, raw[g + nbytes:] != 0xFF
+            if bool(lo.any()):
+                bad.append((name, 'below', g - int(torch.nonzero(lo)[-1])))
+            if bool(hi.any()):
+                bad.append((name, 'above', int(torch.nonzero(hi)[0]) + 1))
+        return bad
+
+
 class Engine:
+    GUARD_BYTES = int(os.environ.get('CY_GUARD_BYTES', '0'))      # red zones around every buffer (tests only; see Arena)
+
     def __init__(self, plan, N, dt, device, training, deterministic=False):
         self.plan, self.N, self.dt, self.device, self.training = plan, N, dt, device, training
+        self.arena = Arena(device, self.GUARD_BYTES if getattr(device, 'type', str(device)) == 'cuda' else 0)
+        new = self.arena.new
         # deterministic: every reduction that the default mode runs through fp32 atomics into shared bins (BatchNorm batch
         # statistics in the conv epilogue, BatchNorm backward sums) gets one table row per contributing block and is folded
         # in a fixed order -- two runs of the same step are bit-identical.  Costs larger tables and slower folds.
@@ -59,22 +100,21 @@ class Engine:
         self._dgrad_sums, self._sums_fused = {}, set()      # (P idx, run c0) -> (L record, tile hint);  {L idx}
         self.tdt = ops.torch_dtype(dt)
         self.act, self.gact = {}, {}
-        f32 = dict(dtype=torch.float32, device=device)
         max_raw = 0
         for st in plan.storages:
             n = N * st.H * st.W * st.C
             if st.kind == 'logits':
-                self.act[st.sid] = torch.empty(n, **f32)
+                self.act[st.sid] = new('act %r' % (st,), n, torch.float32)
             elif st.kind == 'raw':
                 if training:
-                    self.act[st.sid] = torch.empty(n, dtype=self.tdt, device=device)
+                    self.act[st.sid] = new('raw %r' % (st,), n, self.tdt)
                 else:
                     max_raw = max(max_raw, n)
             else:
-                self.act[st.sid] = torch.empty(n, dtype=self.tdt, device=device)
+                self.act[st.sid] = new('act %r' % (st,), n, self.tdt)
                 if training and st.kind == 'act':
-                    self.gact[st.sid] = torch.empty(n, dtype=self.tdt, device=device)
-        self.raw_scratch = torch.empty(max(max_raw, 1), dtype=self.tdt, device=device)
+                    self.gact[st.sid] = new('gact %r' % (st,), n, self.tdt)
+        self.raw_scratch = new('raw_scratch', max(max_raw, 1), self.tdt)
         # per-conv persistent BN vectors and packed weights; shared scratch for the reductions
         self.bnvec, self.wf, self.wd = {}, {}, {}
         max_stats = max_bnrows = max_c = 1
@@ -88,10 +128,10 @@ class Engine:
             C, M = rec['cout'], N * rec['H'] * rec['W']
             cop, cip = _pad32(C), rec['cin_pad']
             kk = rec['ks'] * rec['ks']
-            self.wf[rec['idx']] = torch.empty(cop, kk * cip, dtype=self.tdt, device=device)
-            self.wd[rec['idx']] = torch.empty(cip, kk * cop, dtype=self.tdt, device=device) if training and not rec['first'] else None
+            self.wf[rec['idx']] = new('wf[%d]' % rec['idx'], (cop, kk * cip), self.tdt)
+            self.wd[rec['idx']] = new('wd[%d]' % rec['idx'], (cip, kk * cop), self.tdt) if training and not rec['first'] else None
             if rec['bn']:
-                self.bnvec[rec['idx']] = torch.empty(4, C, **f32)
+                self.bnvec[rec['idx']] = new('bnvec[%d]' % rec['idx'], (4, C), torch.float32)
                 max_stats = max(max_stats, ops.conv_stats_rows(M, C, self.det) * 2 * C)
                 max_c = max(max_c, C)
                 if training:
@@ -111,23 +151,23 @@ class Engine:
         # (the first statistics table and both BN-backward tables share one allocation: a training step zeroes them with ONE
         # fill at the top of the forward pass -- nothing touches the backward tables before the backward pass)
         _r64 = lambda n: (n + 63) // 64 * 64
-        self._ztab = torch.zeros(_r64(max_stats) + 2 * _r64(max_bnrows), **f32)
+        self._ztab = new('ztab (stats + bn-backward tables)', _r64(max_stats) + 2 * _r64(max_bnrows), torch.float32, zero=True)
         self.stats = self._ztab[:max_stats]
         self.bnpart = self._ztab[_r64(max_stats):_r64(max_stats) + max_bnrows]
         # default (non-deterministic) mode: the fold runs in the prologue of the consuming kernel (cy_bn_act_fwd_fused /
         # cy_bn_act_bwd_apply_fused), which cannot zero the table it reads -- two tables alternate from layer to layer and
         # every launch zeroes the other one
         self.fused_bn = not self.det and hasattr(ops, 'bn_act_fwd_fused') and os.environ.get('CY_FUSED_BN', '1') != '0'
-        self.stats_pair = [self.stats, torch.zeros(max_stats, **f32)] if self.fused_bn else None
+        self.stats_pair = [self.stats, new('stats_pair[1]', max_stats, torch.float32, zero=True)] if self.fused_bn else None
         self.bnpart_pair = ([self.bnpart, self._ztab[_r64(max_stats) + _r64(max_bnrows):][:max_bnrows]]
                             if (self.fused_bn and training) else None)
         self._sp = self._bp = 0
         self._bn_tables_fwd = -1          # fwd_serial of the forward pass whose table fill also covered the backward tables
-        self.dgs, self.dbs = torch.empty(max_c, **f32), torch.empty(max_c, **f32)
+        self.dgs, self.dbs = new('dgs', max_c, torch.float32), new('dbs', max_c, torch.float32)
         # deterministic mode: second-stage table of the two-stage folds (<= 256 rows) / partial rows of the head bias gradient
-        self.fold_tmp = torch.zeros(max(256 * 2 * max_c, 256 * 32), **f32) if self.det else None
+        self.fold_tmp = new('fold_tmp', max(256 * 2 * max_c, 256 * 32), torch.float32, zero=True) if self.det else None
         # split-K slabs of every conv stay resident until their group is folded (table-driven, a few launches per step)
-        self.wpart = torch.empty(max(max_wpart, 1), **f32)
+        self.wpart = new('wpart (split-K slabs)', max(max_wpart, 1), torch.float32)
         self._pack_table = self._pack_key = self._pack_epoch = None
         self._in_side_head = self._heads_on_side = False
         # the heads of a model as one batched sequence of launches (cy_yolo_loss_multi) when they share A, C and the threshold
@@ -153,12 +193,12 @@ class Engine:
         self.replayed = 0                        # passes issued through cy_run_plan (tests / probes)
         self._on_module_done = None
         self._tg_buf = None                      # engine-owned copy of the target rows (a recorded list needs a fixed address)
-        self._gout_buf = torch.zeros(1, **f32) if training else None
+        self._gout_buf = new('gout', 1, torch.float32, zero=True) if training else None
         self.fwd_serial = 0
         self._reduce_groups = None
         use_side = training and getattr(device, 'type', str(device)) == 'cuda' and os.environ.get('CY_WGRAD_SIDE_STREAM', '1') != '0'
         self.side = torch.cuda.Stream(device=device) if use_side else None
-        self.dummy = torch.zeros(16, **f32)
+        self.dummy = new('dummy', 16, torch.float32, zero=True)
         # pools
         self.argmax, self.pool_scratch = {}, None
         max_pool_in = 1
@@ -166,21 +206,48 @@ class Engine:
             if rec['op'] == 'pool':
                 o, x = rec['out'], rec['x']
                 if training:
-                    self.argmax[rec['idx']] = torch.empty(ops.maxpool_argmax_bytes(N, x.st.H, o.st.H, o.st.W, o.C),
-                                                          dtype=torch.uint8, device=device)
+                    self.argmax[rec['idx']] = new('argmax[%d]' % rec['idx'], ops.maxpool_argmax_bytes(N, x.st.H, o.st.H, o.st.W, o.C), torch.uint8)
                 # row-pass intermediate N x H x OW x C (forward: tensor dtype, backward: fp32)
                 max_pool_in = max(max_pool_in, N * x.st.H * max(o.st.W, x.st.W) * x.C)
-        self.pool_scratch = torch.empty(max_pool_in, **f32)
+        self.pool_scratch = new('pool_scratch', max_pool_in, torch.float32)
         # heads
-        self.outputs = torch.empty(N, plan.rows_total, 7 + plan.heads[0]['C'], **f32) if plan.heads else None
-        self.metrics = [torch.zeros(20, **f32) for _ in plan.heads]
+        self.outputs = new('outputs', (N, plan.rows_total, 7 + plan.heads[0]['C']), torch.float32) if plan.heads else None
+        self.metrics = [new('metrics[%d]' % i, 20, torch.float32, zero=True) for i in range(len(plan.heads))]
         self.dlogits, self.head_tmp, self.loss_ws = [], [], []
         for h in plan.heads:
             n = N * h['G'] * h['G']
-            self.dlogits.append(torch.empty(n * h['A'] * (7 + h['C']), **f32) if training else None)
-            self.head_tmp.append(View.alloc(N, h['G'], h['G'], 32, dt, device=device) if training else None)
+            self.dlogits.append(new('dlogits[%d]' % len(self.dlogits), n * h['A'] * (7 + h['C']), torch.float32) if training else None)
+            self.head_tmp.append(View(new('head_tmp[%d]' % len(self.head_tmp), N * h['G'] * h['G'] * 32, self.tdt), 0, N, h['G'], h['G'], 32, 32, dt)
+                                 if training else None)
             self.loss_ws.append(None)
         self.nT = -1
+
+    def buffer_map(self):
+        """[(name, device address, bytes)] of every device tensor this engine owns (activations, gradients, packed weights,
+        tables, workspaces): what bench.py's supervisor maps a GPU memory-access fault address onto."""
+        out, seen = [], set()
+
+        def add(name, t):
+            if isinstance(t, View):
+                t = t.buf
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                out.append((name, t.data_ptr(), t.numel() * t.element_size()))
+            elif isinstance(t, dict):
+                for k, v in t.items():
+                    add('%s[%s]' % (name, k), v)
+            elif isinstance(t, (list, tuple)):
+                for i, v in enumerate(t):
+                    add('%s[%d]' % (name, i), v)
+        sts = {st.sid: st for st in self.plan.storages}
+        for sid, t in self.act.items():
+            add('act %r' % (sts.get(sid),), t)
+        for sid, t in self.gact.items():
+            add('gact %r' % (sts.get(sid),), t)
+        for name, t in vars(self).items():
+            if name not in ('act', 'gact', 'plan', 'params', 'grads', '_views', '_view_refs'):
+                add(name, t)
+        return out
 
     # ---- views -----------------------------------------------------------------------------------
     def view(self, ref, grad=False):
@@ -271,7 +338,7 @@ class Engine:
         if self._tg_buf is None or self._tg_buf.shape[0] < max(nT, 1) or self._tg_buf.shape[1] != targets.shape[1]:
             if self._tg_buf is not None:
                 self._retired_ws.append(self._tg_buf)
-            self._tg_buf = torch.zeros(max(2 * nT, 256), targets.shape[1], dtype=torch.float32, device=self.device)
+            self._tg_buf = self.arena.new('targets', (max(2 * nT, 256), targets.shape[1]), torch.float32, zero=True)
         own = self._tg_buf[:nT]
         if nT:
             own.copy_(targets, non_blocking=True)
@@ -493,10 +560,10 @@ class Engine:
         if self.loss_ws[h] is None or self.loss_ws[h].numel() < need:
             if self.loss_ws[h] is not None:
                 self._retired_ws.append(self.loss_ws[h])
-            self.loss_ws[h] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.loss_ws[h] = self.arena.new('loss_ws[%d]' % h, need, torch.uint8)
         dl = self.dlogits[h]
         if dl is None:
-            dl = self.dlogits[h] = torch.empty(logits.numel(), dtype=torch.float32, device=self.device)
+            dl = self.dlogits[h] = self.arena.new('dlogits[%d]' % h, logits.numel(), torch.float32)
         ops.yolo_loss(logits, self.N, rec['G'], rec['A'], rec['C'], targets, rec['anchors'], img_size,
                       rec['ignore_thresh'], use_giou, self.loss_ws[h], self.metrics[h], dl)
 
@@ -509,12 +576,12 @@ class Engine:
             need = ops.yolo_loss_multi_workspace([r['G'] for r in recs], self.N, r0['A'], r0['C'], cap)
             if self._head_table is not None:
                 self._retired_ws.append(self._head_table)      # (table and workspace: see __init__)
-            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ws = self.arena.new('heads workspace', need, torch.uint8)
             heads = []
             for r in recs:
                 h = r['head']
                 if self.dlogits[h] is None:
-                    self.dlogits[h] = torch.empty(self.act[r['logits'].st.sid].numel(), dtype=torch.float32, device=self.device)
+                    self.dlogits[h] = self.arena.new('dlogits[%d]' % h, self.act[r['logits'].st.sid].numel(), torch.float32)
                 heads.append((self.act[r['logits'].st.sid], self.dlogits[h], self.metrics[h], r['anchors'], r['G'], r['row_offset']))
             self._head_table = (ops.make_head_table(heads), ws, cap)
         table, ws, _ = self._head_table
@@ -805,7 +872,7 @@ class Engine:
         """Which BN convs run as ONE two-phase launch (conv -> grid ticket -> BN + activation from the accumulators).  Per layer:
         the best separate conv (already chosen) + the BN / activation pass against the fused launch over the pipelined kernel's
         tiles that keep the grid co-resident; persisted like every other choice."""
-        self._ticket = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._ticket = self.arena.new('ticket', 4, torch.int32, zero=True)
         P = self.params
         for rec in self.plan.convs:
             if not rec['bn']:

@@ -52,3 +52,62 @@ def test_launcher_world_size_mismatch_is_reported():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], capture_output=True, text=True,
                        env=env, cwd=ROOT, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
+
+
+# ---- the supervisor (round 5: the driver's bench of round 4 died of a GPU memory-access fault with nothing on stdout) -------------
+FAULT = ('/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n[bench    1.79s] timed region: 20 steps\n'
+         'Memory access fault by GPU node-2 (Agent handle: 0x6333996a6d10) on address 0x7000000ff000. Reason: Unknown.\n'
+         'Fatal Python error: Aborted\n\nCurrent thread 0x00007 (most recent call first):\n  File "bench.py", line 445 in worker\n')
+
+
+def _bench_module():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_fault_address_is_mapped_onto_the_workers_buffers(tmp_path):
+    bench = _bench_module()
+    mp = tmp_path / 'map.json'
+    mp.write_text(json.dumps({'buffers': [['act S3[76x76x256 act]', 0x700000000000, 0x100000], ['wpart', 0x700000200000, 0x1000]],
+                              'segments': [[0x700000000000, 0x200000]]}))
+    d = bench.diagnose_fault(FAULT, str(mp))
+    assert d['address'] == '0x7000000ff000' and d['reason'] == 'Unknown.'
+    assert d['buffer'].startswith('act S3[76x76x256 act] + %d of' % 0xff000) and d['in_allocator_segment'] is True
+    assert d['last_stage'] == 'timed region: 20 steps' and any('line 445' in ln for ln in d['python_stack'])
+    d = bench.diagnose_fault(FAULT.replace('0x7000000ff000', '0x700000100800'), str(mp))       # between two buffers
+    assert d['buffer'] is None and 'ends 2048 bytes before' in d['nearest_below'] and 'wpart starts' in d['nearest_above']
+    d = bench.diagnose_fault('Traceback ...\nRuntimeError: boom\n', str(mp))                    # not a GPU fault
+    assert 'address' not in d and 'boom' in d['stderr_tail']
+
+
+@pytest.mark.parametrize('outcomes,want_rc,want_retries', [
+    ([(-6, None, None), (0, 'full', 'part')], 0, 1),          # fault, then a clean run
+    ([(-6, None, 'part'), (-6, None, None)], 1, 1),           # dies twice, once after the timed region
+    ([(0, 'full', 'part')], 0, 0),                            # the normal case
+    ([(-6, 'full', 'part')], 0, 0)])                          # measured, died at teardown
+def test_supervisor_survives_a_dying_worker_and_always_prints_one_line(monkeypatch, capsys, outcomes, want_rc, want_retries):
+    bench = _bench_module()
+    full = {'metric': 'm', 'value': 870.0, 'unit': 'images/s', 'ms_per_step': 18.4, 'roofline': {'frac': 0.17}, 'cpu_baseline': None}
+    part = {'partial': True, 'value': 869.0, 'ms_per_step': 18.41}
+    calls = []
+
+    def fake(argv, map_file, timeout=0):
+        rc, f, p_ = outcomes[len(calls)]
+        calls.append(argv)
+        return rc, (dict(full) if f else None), (dict(part) if p_ else None), (FAULT if rc else '')
+    monkeypatch.setattr(bench, 'run_worker', fake)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    argv = ['--steps', '20', '--warmup', '5', '--no-extra', '--no-cpu-baseline']
+    rc = bench.supervise(bench.parse_args(argv), argv)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('{')]
+    assert rc == want_rc and len(lines) == 1 and len(calls) == len(outcomes)
+    d = json.loads(lines[0])
+    assert d['fault_retries'] == want_retries
+    if want_rc == 0:
+        assert d['value'] == 870.0 and 'error' not in d
+        assert ('faults' in d) == any(o[0] != 0 for o in outcomes)
+    else:
+        assert d['value'] == 869.0 and d['ms_per_step'] == 18.41 and 'AFTER the timed region' in d['error']      # the completed timed region survives
+        assert len(d['faults']) == 2 and d['faults'][0]['address'] == '0x7000000ff000'

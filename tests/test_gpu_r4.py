@@ -1,8 +1,8 @@
 """Round-4 GPU evidence (VERDICT r3 "next round" #1, #2, #7 and ADVICE r3):
 
-* the BENCHMARKED 16-bit modes against the fp32 parity mode on a CONDITIONED complex_yolov4.cfg (50 Adam steps from the seeded
-  init) where element-wise agreement is possible: flat-gradient cosine, loss, decoded probabilities;
-* convergence A/B: 100 steps f16 against f32 on the same four batches;
+* (the training-dynamics comparisons of the 16-bit modes -- conditioned net, ideal-storage control, convergence A/B -- live in
+  tests/test_zz_gpu_dynamics.py, which collects LAST: a chaotic-trajectory test must never again stop `-x` before the kernel,
+  replay and configs[3] tests below, as it did in GPUTEST_r04)
 * BASELINE configs[3] (batch 32, 608x608 inference + rotated NMS) against THE REFERENCE's eval forward + post_processing_v2
   (tests/golden/darknet_eval.npz), f32 eval path and the f16 fused-eval path with static_eval_weights;
 * a canary for the shipped stream configuration of the heads;
@@ -25,158 +25,6 @@ from tests.test_gpu_r2 import DEV, _model  # noqa: E402
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 B, S = 16, 608
-N_STEPS, SNAP_AT = 100, 50
-
-
-def _batches(n=4, seed0=70):
-    return [(syn.bev_images(B, S, seed=seed0 + i).to(DEV), syn.targets(B, 6, S, seed=seed0 + i).to(DEV)) for i in range(n)]
-
-
-def _train(dtype, steps, snap_at=(), deterministic=True):
-    """`steps` FusedAdam steps (lr 1e-3, the reference's default, train_config.py:82-94) of complex_yolov4.cfg at 608x608 batch
-    16 from the seeded init over four fixed batches.  -> (losses, {n: state-dict snapshot after n steps for n in snap_at})."""
-    from complex_yolov4_pytorch_amd.optim import FusedAdam
-    model = _model('complex_yolov4.cfg', dtype, deterministic=deterministic)
-    model.train()
-    opt = FusedAdam(model.parameters(), lr=1e-3)
-    data = _batches()
-    losses, snaps = [], {}
-    for i in range(steps):
-        x, tg = data[i % len(data)]
-        opt.zero_grad(set_to_none=True)
-        loss, _ = model(x, tg)
-        loss.backward()
-        opt.step()
-        losses.append(loss.detach().reshape(-1)[0])
-        if i + 1 in snap_at:
-            snaps[i + 1] = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    losses = [float(v) for v in torch.stack(losses).cpu()]
-    model.release_engines()
-    del opt, model
-    torch.cuda.empty_cache()
-    return losses, snaps
-
-
-@pytest.fixture(scope='module')
-def f32_run():
-    return _train('f32', N_STEPS, snap_at=(SNAP_AT, N_STEPS))
-
-
-def _one_step(dtype, snap, deterministic, batch, loss_scale=None):
-    model = _model('complex_yolov4.cfg', dtype, deterministic=deterministic, loss_scale=loss_scale)
-    model.load_state_dict(snap)
-    model.train()
-    x, tg = batch
-    loss, out = model(x, tg)
-    loss.backward()
-    res = (float(loss.detach().reshape(-1)[0]), out.detach().clone(), model.flat_grad.detach().double().clone())
-    model.release_engines()
-    del model
-    torch.cuda.empty_cache()
-    return res
-
-
-def _agreement(a, b):
-    """(flat-gradient cosine, gradient norm ratio, loss rel, probabilities max |d|, median |d|) of step result a against b."""
-    (la, oa, ga), (lb, ob, gb) = a, b
-    dp = (oa[..., 6:] - ob[..., 6:]).abs()
-    return (float((ga * gb).sum() / (ga.norm() * gb.norm())), float(ga.norm() / gb.norm()), abs(la - lb) / abs(lb), float(dp.max()),
-            float(dp.median()))
-
-
-# What the 16-bit modes hold against the fp32 parity mode on the conditioned net, ONE step on a batch of the conditioning run.
-# VERDICT r3 next #1a asked cosine >= 0.99 (f16) / 0.97 (bf16), loss 2e-3, probabilities 2e-2 and "if even a conditioned net does
-# not agree, that is a finding".  It is: measured on the MI355X over four sessions f16 0.958-0.965 / 0.960-0.973 (50 / 100 steps), bf16
-# 0.71-0.76 / 0.75-0.79, loss rel 1e-4...9e-4 (f16) and 3e-4...1.3e-2 (bf16), probabilities max 3.0e-2 (f16).  What it is a finding ABOUT is settled by two controls in the same test: (1) the fp32
-# default mode (atomics) against the fp32 deterministic mode gives 0.99993 -- the snapshot is well conditioned for float32;
-# (2) the REFERENCE'S OWN float32 arithmetic with ideal 16-bit storage of the tensors a half-precision implementation keeps in
-# memory (oracle storage_round: conv inputs, weights copies, pre-BN outputs and their gradients rounded, everything else
-# float32) deviates from float32 by the same angle -- see test_16bit_step_matches_ideal_16bit_storage.  The bounds below are
-# the measured values with margin.
-COND = {'f16': dict(cos=0.93, loss=2e-3, prob=5e-2), 'bf16': dict(cos=0.55, loss=3e-2, prob=0.35)}
-
-
-def test_conditioned_net_16bit_step_agrees_with_fp32(f32_run):
-    """At the seeded random init complex_yolov4.cfg amplifies a 1e-7 perturbation to 4e-2 in the gradients (the ORACLE's own
-    float32 run differs from its float64 run by that much: profiles/r04_oracle_f64_vs_f32.txt), so the 16-bit modes could only
-    be bounded by norms there (tests/test_gpu_r3.py).  After 50 / 100 Adam steps in the fp32 parity mode the net is
-    conditioned on its four batches; ONE step from those snapshots in f32 (deterministic parity mode), f16 and bf16 (the
-    benchmarked default mode) is compared element-wise: flat-gradient cosine, loss, decoded probabilities -- on a batch of the
-    conditioning run (asserted) and on an unseen batch (printed).  Two more columns say what the comparison can resolve: the
-    fp32 default mode (atomics) against the fp32 deterministic mode, and a REPEAT of the f16 step against the first f16 step."""
-    losses, snaps = f32_run
-    assert losses[SNAP_AT - 1] < 0.5 * losses[0], losses[:SNAP_AT:7]
-    seen, unseen = _batches(1, seed0=70)[0], _batches(1, seed0=80)[0]
-    table = {}
-    for n in (SNAP_AT, N_STEPS):
-        for bname, batch in (('seen', seen), ('unseen', unseen)):
-            ref = _one_step('f32', snaps[n], True, batch)
-            row = {'f16': _agreement(_one_step('f16', snaps[n], False, batch), ref),
-                   'bf16': _agreement(_one_step('bf16', snaps[n], False, batch), ref)}
-            if bname == 'seen':
-                row['f16 loss_scale 256'] = _agreement(_one_step('f16', snaps[n], False, batch, loss_scale=256.0), ref)
-                row['f32 default'] = _agreement(_one_step('f32', snaps[n], False, batch), ref)
-                f16a = _one_step('f16', snaps[n], False, batch)
-                row['f16 repeat vs f16'] = _agreement(_one_step('f16', snaps[n], False, batch), f16a)
-            table[(n, bname)] = (ref[0], row)
-    for (n, bname), (l32, row) in table.items():
-        for mode, (cos, nr, rel, pmax, pmed) in row.items():
-            print('conditioned v4 (f32, %3d Adam steps: loss %.1f -> %.1f), %-6s batch (f32 loss %8.3f): %-17s vs f32 det: gradient cosine '
-                  '%.5f, norm ratio %.4f, loss rel %.2e, probabilities |d| max %.2e median %.2e'
-                  % (n, losses[0], losses[n - 1], bname, l32, mode, cos, nr, rel, pmax, pmed))
-    for dtype, b in COND.items():
-        cos, _, rel, pmax, _ = table[(SNAP_AT, 'seen')][1][dtype]
-        assert cos >= b['cos'], (dtype, cos)
-        assert rel <= b['loss'], (dtype, rel)
-        assert pmax <= b['prob'], (dtype, pmax)
-
-
-@pytest.mark.parametrize('dtype,tdt', [('f16', torch.float16), ('bf16', torch.bfloat16)])
-def test_16bit_step_matches_ideal_16bit_storage(f32_run, dtype, tdt):
-    """Is the 16-bit step's distance from float32 the kernels' doing, or what 16-bit STORAGE does to this function?  Same
-    conditioned snapshot (50 steps), batch of 4 (what the CPU oracle finishes in seconds).  Device: f16 / bf16 default mode
-    against the fp32 parity mode.  Oracle: the reference's float32 arithmetic with every conv input, weight copy and pre-BN
-    output -- and the gradients flowing through them -- rounded to the 16-bit type, against the same arithmetic without
-    rounding.  The device's gradient cosine must be no worse than the ideal-storage one minus a margin (0.06 for f16; 0.15 for
-    bf16, whose cosine itself moves by +-0.1 with the last bits of the snapshot: 0.50 / 0.68 for the ideal storage, 0.57 / 0.60 /
-    0.62 for the device over three sessions), the probability error medians within a factor of two."""
-    from complex_yolov4_pytorch_amd.models.darknet_utils import parse_cfg
-    from oracle import darknet_ref
-    from tests.util import storage_round
-    _, snaps = f32_run
-    snap = snaps[SNAP_AT]
-    x, tg = syn.bev_images(4, S, seed=70), syn.targets(4, 6, S, seed=70)
-    batch = (x.to(DEV), tg.to(DEV))
-    dev = _agreement(_one_step(dtype, snap, False, batch), _one_step('f32', snap, True, batch))
-    net = darknet_ref.DarknetRef(parse_cfg(os.path.join(ROOT, 'complex-yolov4-pytorch_amd', 'config', 'cfg', 'complex_yolov4.cfg')))
-    ps, bs = net.param_shapes()
-    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-
-    def oracle(rnd):
-        params = {k: snap[k].detach().float().cpu().clone().requires_grad_(True) for k in ps}
-        bufs = {k: snap[k].detach().float().cpu().clone() for k in bs}
-        out, loss, _ = net.forward(params, x, tg, True, True, bufs, storage_round=rnd)
-        loss.sum().backward()
-        return float(loss.detach().sum()), out.detach(), torch.cat([params[k].grad.reshape(-1).double() for k in ps])
-    ideal = _agreement(oracle(storage_round(tdt)), oracle(None))
-    print('conditioned v4 (%d steps), batch 4: %s device vs fp32 parity mode: gradient cosine %.5f, loss rel %.2e, probabilities |d| max %.2e '
-          'median %.2e;  ORACLE float32 arithmetic with ideal %s storage vs without: cosine %.5f, loss rel %.2e, probabilities max %.2e median %.2e'
-          % (SNAP_AT, dtype, dev[0], dev[2], dev[3], dev[4], dtype, ideal[0], ideal[2], ideal[3], ideal[4]))
-    assert dev[0] >= ideal[0] - (0.06 if dtype == 'f16' else 0.15), (dev[0], ideal[0])
-    assert dev[4] <= 2.0 * ideal[4] + 1e-4 and dev[3] <= 3.0 * ideal[3] + 1e-3      # (medians within 2 x; the maxima, noisier, within 3 x)
-
-
-def test_f16_converges_like_fp32(f32_run):
-    """100 steps over the same four batches from the same init: the f16 default mode's final loss (mean over the last four
-    steps = one pass over the batches) within 10 % of the fp32 parity mode's (VERDICT r3 next #1b)."""
-    l32, _ = f32_run
-    l16, _ = _train('f16', N_STEPS, deterministic=False)
-    f32_final, f16_final = float(np.mean(l32[-4:])), float(np.mean(l16[-4:]))
-    print('v4 608x608 B16, %d Adam steps on 4 batches: loss f32 %.2f -> %.3f, f16 %.2f -> %.3f (ratio %.3f); at step 25: %.2f / %.2f, '
-          'step 50: %.2f / %.2f' % (N_STEPS, l32[0], f32_final, l16[0], f16_final, f16_final / f32_final, l32[24], l16[24], l32[49], l16[49]))
-    assert all(np.isfinite(l16)) and all(np.isfinite(l32))
-    assert f32_final < 0.1 * l32[0] and f16_final < 0.1 * l16[0]
-    assert 0.88 <= f16_final / f32_final <= 1.12       # (asked: 10 %; three sessions gave 0.955, 1.043, 1.044 -- the f16 run is not bit-reproducible)
 
 
 # ---- BASELINE configs[3]: inference batch 32 at 608x608 + rotated NMS against the reference ---------------------------------
@@ -287,6 +135,24 @@ def test_inference_b32_608_against_reference(golden, dtype):
         print('  images 0-1: rows on the other side of the confidence threshold than in float32: device f16 %d, ideal f16 storage %d (of %d candidates)'
               % (d_mine, d_ideal, int(c32.sum())))
         assert d_mine <= 1.5 * d_ideal + 8          # (measured: 81 vs 68 of 140)
+        # END TO END on those two images (VERDICT r4 next #2d): the float32 oracle's detections (its outputs through the device
+        # NMS) are the reference; how many of them survive ideal f16 storage is the control, and the f16 device path must find
+        # as many, with no more spurious ones -- bound = control x margin, stated below
+        nms_t = float(g['nms_thresh'][0])
+
+        def e2e(rows):
+            dets = post_processing_v2(rows.to(DEV).float().contiguous(), conf_thresh=thr0, nms_thresh=nms_t)
+            return [None if d is None else d.numpy() for d in dets]
+        ref32, ideal16, dev16 = e2e(o32), e2e(o16), e2e(out[:2])
+        tot = sum(0 if r is None else len(r) for r in ref32)
+        f_i = sum(_match(d, r, 0.05) for d, r in zip(ideal16, ref32) if r is not None)
+        f_d = sum(_match(d, r, 0.05) for d, r in zip(dev16, ref32) if r is not None)
+        x_i = sum(0 if d is None else len(d) for d in ideal16) - f_i
+        x_d = sum(0 if d is None else len(d) for d in dev16) - f_d
+        print('  images 0-1 end to end vs the float32 oracle\'s %d detections: found %d (device f16) / %d (ideal f16 storage); unmatched '
+              '%d (device) / %d (ideal)' % (tot, f_d, f_i, x_d, x_i))
+        E2E_MARGIN = 0.85       # the device finds at least 85 % of what ideal storage finds (minus 2 rows), spurious <= ideal / 0.85 + 2
+        assert f_d >= E2E_MARGIN * f_i - 2 and x_d <= x_i / E2E_MARGIN + 2, (tot, f_d, f_i, x_d, x_i)
     # (2) threshold crossings
     thr = float(g['conf_thresh'][0])
     mine = set(torch.nonzero(flat[:, 6] >= thr).reshape(-1).cpu().tolist())
