@@ -3,6 +3,7 @@ of truth for the C ABI); there is NO fallback: if the library is missing or a ca
 import ctypes
 import os
 import re
+import threading
 
 # PyTorch must load ITS HIP runtime first: libcyolo_hip.so links libamdhip64.so.7 by soname, and if the system copy
 # under /opt/rocm is mapped before torch's bundled one, torch later finds "No HIP GPUs".  Importing torch here makes
@@ -113,7 +114,17 @@ _DBL, _DBLP = _struct.Struct('<q'), _struct.Struct('<d')
 
 
 class _Lib:
-    recorder = None       # a PlanRecorder while an engine records a pass
+    # a PlanRecorder while an engine records a pass -- of the recording THREAD only (a prefetch thread rasterising
+    # the next batch, or an eval engine in another thread, must neither be recorded into the training program nor be refused)
+    _rec = threading.local()
+
+    @property
+    def recorder(self):
+        return getattr(self._rec, 'r', None)
+
+    @recorder.setter
+    def recorder(self, r):
+        self._rec.r = r
 
     def fn_index(self, name):
         i = self._fn_index.get(name)

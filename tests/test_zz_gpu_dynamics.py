@@ -191,3 +191,41 @@ def test_f16_converges_like_fp32(f32_run):
     m32, m16 = float(np.mean(list(fin32.values()))), float(np.mean(list(fin16.values())))
     print('mean final loss over %d batch sets: f32 %.3f, f16 %.3f (ratio %.3f; bound: <= 1.15, one-sided)' % (len(CONV_SEEDS), m32, m16, m16 / m32))
     assert m16 <= 1.15 * m32
+
+
+def test_f16_inference_detections_match_fp32_on_the_conditioned_net(f32_run):
+    """End to end, f16 against float32, where the comparison means something (VERDICT r4 next #2d): on the random-init net of the
+    configs[3] golden even IDEAL f16 storage keeps 2 of 140 float32 detections, so tests/test_gpu_r4.py can only compare error
+    statistics there.  The conditioned net (100 Adam steps in the fp32 parity mode, running statistics included) has confident
+    boxes: model.eval() + post_processing_v2 (rotated merge-NMS on the device) in the f16 fused-eval path with static_eval_weights
+    -- the benchmarked inference path -- against the f32 parity eval path (itself pinned to the reference's eval forward by
+    test_inference_b32_608_against_reference[f32]), batch 16 at 608 x 608, a batch of the conditioning run.  Bounds: the f16 path
+    finds >= 90 % of the f32 detections (same class, box within 5 % relative) and adds <= 10 % (+ 2) of its own; sized on the
+    probabilities' max |d| of 3e-2 that the conditioned-net step test measures for f16 (a detection within 3e-2 of the 0.5
+    threshold may flip: a few per cent of ~100)."""
+    from complex_yolov4_pytorch_amd.utils.evaluation_utils import post_processing_v2
+    from tests.test_gpu_r4 import _match
+    _, snaps = f32_run
+    x = _batches(1, seed0=70)[0][0]
+    dets = {}
+    for dtype in ('f32', 'f16'):
+        model = _model('complex_yolov4.cfg', dtype)
+        model.load_state_dict(snaps[N_STEPS])
+        model.eval()
+        model.cpu_outputs = False
+        model.static_eval_weights = dtype != 'f32'
+        with torch.no_grad():
+            out = model(x)
+            out = model(x)               # (second batch: the cached weight pack, as benchmarked)
+        d = post_processing_v2(out, conf_thresh=0.5, nms_thresh=0.5)
+        dets[dtype] = [None if r is None else r.numpy() for r in d]
+        model.release_engines()
+        del model
+        torch.cuda.empty_cache()
+    total = sum(0 if r is None else len(r) for r in dets['f32'])
+    found = sum(_match(d, r, 0.05) for d, r in zip(dets['f16'], dets['f32']) if r is not None)
+    extra = sum(0 if d is None else len(d) for d in dets['f16']) - found
+    print('conditioned v4 (%d steps), eval B16 608 + post_processing_v2(0.5, 0.5): f32 path %d detections; f16 fused-eval path finds %d of them, '
+          '%d unmatched of its own' % (N_STEPS, total, found, extra))
+    assert total >= 16, 'the conditioned net should be confident about most of its 96 training boxes'
+    assert found >= 0.9 * total and extra <= 0.1 * total + 2
