@@ -128,7 +128,12 @@ def test_train_step_is_batch_permutation_invariant_fp32():
     """Permuting the images (and the sample index of the targets) leaves loss and gradients unchanged: BN statistics,
     target assignment and the reductions do not depend on sample order (tiny cfg, fp32: tight)."""
     l1, l2, rel = _perm_step('complex_yolov4_tiny.cfg', 'f32', 4, 608)
-    assert abs(l1 - l2) / l1 < 1e-5 and rel < 5e-3
+    # The loss is tight.  The gradient bound is NOT a kernel tolerance: a permutation changes the summation order of the BatchNorm
+    # statistics, a pre-activation next to the leaky-ReLU kink may change side, and the gradient then moves discontinuously along
+    # that path -- measured over ten runs on the MI355X (round 5): 1.1e-3 ... 2.1e-3 nine times, 8.2e-3 once (which failed the
+    # former 5e-3 bound as the 6th test of a `pytest -x` run).  A sample-order dependence of the statistics, the target
+    # assignment or a reduction would show up at O(1).
+    assert abs(l1 - l2) / l1 < 1e-5 and rel < 3e-2
 
 
 def test_full_size_train_step_permutation_invariant_loss():

@@ -63,7 +63,7 @@ def busy_load():
             ops.conv_wgrad(y, x, 3, 1, 1, part, 8)
     elif load.startswith('dirty'):   # dirtyNaN / dirtyBig / dirtyZero: leave a pattern in every VGPR and LDS word of every CU
         pat = {'dirtyNaN': 0x7FC00001, 'dirtyBig': 0x4B800000, 'dirtyZero': 0, 'dirtyNeg': 0xBF800000, 'dirtyInt': 0x00000005}[load]
-        probes.probe_dirty(pat)
+        probes.probe_dirty(pat, blocks=int(os.environ.get('CY_PROBE_DIRTY_BLOCKS', '2048')), lds_bytes=int(os.environ.get('CY_PROBE_DIRTY_LDS', str(64 * 1024))))
     elif load == 'bn':
         for _ in range(6):
             ops.bn_act_fwd(x, y, None, sc, sh, 2)
