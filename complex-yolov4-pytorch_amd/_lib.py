@@ -12,7 +12,7 @@ import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_HERE, '..', 'include', 'cyolo_hip.h')
-LIBPATH = os.path.join(_HERE, 'csrc', 'libcyolo_hip.so')
+LIBPATH = os.environ.get('CY_LIBPATH') or os.path.join(_HERE, 'csrc', 'libcyolo_hip.so')      # (CY_LIBPATH: A/B builds, tools/)
 
 _SCALARS = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'cy_stream_t': ctypes.c_void_p,
             'int32_t': ctypes.c_int32, 'uint32_t': ctypes.c_uint32}

@@ -17,7 +17,20 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, 
 # 64-thread launch bounds) every array is a register vector: ScratchSize 0.
 _ALLOCA = ['-mllvm', '-amdgpu-promote-alloca-to-vector-limit=1024']
 _REMARKS = ['-Rpass-analysis=kernel-resource-usage']
-EXTRA_FLAGS = {src: _REMARKS + (_ALLOCA if src in ('yolo_head.hip', 'riou_nms.hip') else []) for src in SOURCES}
+# -fno-slp-vectorize for the geometry / head / rasteriser kernels (round 5, profiles/r05_head_race.txt): hipcc's SLP vectoriser turns
+# their float32 chains into PACKED-f32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel shuffles: 2703 of
+# them in yolo_head.hip), and on the MI355X those returned wrong values in lanes 48-63 of a wave in 0.7 % of launches whenever an
+# MFMA-heavy wave of ANOTHER kernel shared the SIMD (igemm_fast<192,128> or the 384 x 128 pipelined tile on a second stream; never
+# alone) -- the "head race" of rounds 2-4, whose mechanism was unknown.  Built without SLP (4 packed instructions left) the same
+# probe is clean: 0 of 2999 repeats against 8 / 1499, 11 / 1499, 10 / 999 with it, results bit-identical.  These kernels are
+# latency-bound one-wave chains: the scalar forms cost nothing.  The BatchNorm / activation passes and the conv epilogues keep the
+# packed forms (0.4-0.6 % of the step, tools/r5_ab_lib.sh): they were never seen to differ beside the same aggressors
+# (tools/victim_probe.py, 0 / 1499 each) nor in 5000 bit-identical repeats of the whole two-stream step; CY_BUILD_NO_SLP=1 builds
+# every file without SLP for whoever wants the belt as well as the braces.
+_NO_SLP = ['-fno-slp-vectorize']
+_NO_SLP_FILES = ('yolo_head.hip', 'riou_nms.hip', 'bev.hip')
+EXTRA_FLAGS = {src: _REMARKS + (_ALLOCA if src in ('yolo_head.hip', 'riou_nms.hip') else []) +
+               (_NO_SLP if (src in _NO_SLP_FILES or os.environ.get('CY_BUILD_NO_SLP') == '1') else []) for src in SOURCES}
 # NO kernel of the library may come out of the compiler with a private segment (scratch): checked on every compile of every
 # file (check_scratch).  Round 2 found the head kernels' results to depend on what ran beside them while they spilled; round 3
 # found two conv instantiations that had quietly acquired spills (a 384 x 128 direct-store epilogue, 196 bytes per lane) while
@@ -129,7 +142,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
-        if force or _mtime(o) < max(_mtime(s), hdr_time):
+        if force or _mtime(o) < max(_mtime(s), hdr_time, _mtime(os.path.abspath(__file__))):      # (this file holds the per-file flags)
             cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
