@@ -560,6 +560,7 @@ def worker(a):
 
     fused_layers = max((len(e._sums_fused) for e in model._engines.values()), default=0)
     replayed = sum(getattr(e, 'replayed', 0) for e in model._engines.values())
+    passes = sum(getattr(e, 'passes', 0) for e in model._engines.values())
     for e in model._engines.values():
         e.check_grid_waits()
     sf_all = step_flops(model)         # per-GPU algorithmic FLOPs of one step (weak scaling: the same on every rank)
@@ -575,7 +576,7 @@ def worker(a):
                        'global_batch': world * a.batch, 'parallelism': 'dp%d' % world, 'loss_final': round(final_loss, 4),
                        'deterministic': bool(a.deterministic),
                        'issue': graph_note if graphed is not None or not replayed else
-                       'recorded launch lists replayed from C (cy_run_plan): every kernel still launches eagerly, %d passes replayed' % replayed,
+                       'recorded launch lists replayed from C (cy_run_plan): every kernel still launches eagerly, %d of %d passes replayed' % (replayed, passes),
                        'dgrad_bn_sums_layers': fused_layers,
                        'yolo_outputs': 'stay on the device in training (the reference copies 14.6 MB to the host every step, '
                                        'darknet2pytorch.py:228, and train.py discards them)'},

@@ -34,6 +34,18 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static inline hipStream_t cy_s(cy_stream_t s) { return (hipStream_t)s; }
 
+// One-time per-kernel set-up (hipFuncSetAttribute of the dynamic LDS size) is per DEVICE: a process that drives several GPUs
+// (not the one-process-per-GPU layout bench.py uses, but the C ABI does not forbid it) must repeat it on each.  `mask` is the
+// caller's function-static word, bit d = done on device d.
+static inline bool cy_first_use_on_device(unsigned long long& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (mask & bit) return false;
+    mask |= bit;
+    return true;
+}
+
 // ---- element traits: 16-byte chunk = CH elements ------------------------------------------------
 template <typename T>
 struct Elem;

@@ -236,11 +236,10 @@ template <typename T, int CIN, int COUT, int S, int TH, int TW, int SPW>
 int direct_launch(const IgemmParams& p, hipStream_t s) {
     typedef DirectCfg<T, CIN, COUT, S, TH, TW, SPW> C;
     static_assert(C::SMEM <= 80 * 1024, "two blocks per CU");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;      // bit d: set for HIP device d
+    if (cy_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct3x3_kernel<T, CIN, COUT, S, TH, TW, SPW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        attr_done = true;
     }
     const long tiles = (long)p.N * ((p.OH + TH - 1) / TH) * ((p.OW + TW - 1) / TW);
     const int slots = 256 * C::BLOCKS_PER_CU;                     // persistent blocks: every CU slot, each looping over tiles
@@ -528,11 +527,10 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
 template <typename T, int CIN, int COUT, int SPW, bool EXTRA>
 int pw_launch_x(const IgemmParams& p, hipStream_t s) {
     typedef PwCfg<T, CIN, COUT, SPW> C;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;      // bit d: set for HIP device d
+    if (cy_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct1x1_kernel<T, CIN, COUT, SPW, EXTRA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        attr_done = true;
     }
     const long tiles = (p.M + C::TP - 1) / C::TP;
     const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
@@ -788,11 +786,10 @@ __global__ void __launch_bounds__(256, 2) direct_s2dgrad_kernel(const IgemmParam
 template <typename T, int GC, int OC>
 int s2dgrad_launch(const IgemmParams& p, hipStream_t s) {
     typedef S2Cfg<T, GC, OC> C;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;      // bit d: set for HIP device d
+    if (cy_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_s2dgrad_kernel<T, GC, OC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        attr_done = true;
     }
     const long tiles = (long)p.N * ((p.OH + C::THO - 1) / C::THO) * ((p.OW + C::TWO - 1) / C::TWO);
     const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);

@@ -350,11 +350,10 @@ int launch_general(const IgemmParams& p0, hipStream_t s) {
     p.mtiles = ((p.M + BM - 1) / BM) * p.ncls;
     p.ntiles = (p.OC + BN - 1) / BN;
     constexpr int smem = 2 * (BM + BN) * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;      // bit d: set for HIP device d
+    if (cy_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, s, p);
     CY_LAUNCH_CHECK();
@@ -367,11 +366,10 @@ int launch_fast(const IgemmParams& p0, hipStream_t s) {
     p.mtiles = ((p.M + BM - 1) / BM) * p.ncls;
     p.ntiles = (p.OC + BN - 1) / BN;
     constexpr int smem = 2 * (BM + BN) * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;      // bit d: set for HIP device d
+    if (cy_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fast_kernel<T, BM, BN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     hipLaunchKernelGGL((igemm_fast_kernel<T, BM, BN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, s, p);
     CY_LAUNCH_CHECK();

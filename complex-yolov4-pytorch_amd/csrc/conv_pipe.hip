@@ -444,6 +444,10 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
                 }
             }
             __syncthreads();
+            // A wait that gave up (ticket[2], set above by the block it happened to) must not pass silently: the
+            // statistics may be incomplete, so every block that sees the flag normalises with NaN -- the layer's output, the
+            // loss and every gradient of the step turn NaN, which no training loop overlooks.
+            const bool broken = __hip_atomic_load(p.ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             float* bnv = reinterpret_cast<float*>(smem + 8 * (WROWS * ROWB));      // [2][BN]: scale, shift (behind the store tiles)
             double* bsum = reinterpret_cast<double*>(bnv + 2 * BN);                  // [2][BN]: sum, sum of squares
             static_assert(8 * WROWS * ROWB + 2 * BN * 4 + 2 * BN * 8 <= NST * STAGE, "the BN vectors fit behind the store tiles");
@@ -472,7 +476,7 @@ __global__ void __launch_bounds__(512 + 64 * LOADERS, LOADERS ? 3 : 2) igemm_pip
                     double var = sq / cnt - m * m;
                     if (var < 0.0) var = 0.0;
                     const float is = (float)(1.0 / sqrt(var + (double)p.bn_eps));
-                    sc = p.bn_gamma[c] * is;
+                    sc = broken ? __builtin_nanf("") : p.bn_gamma[c] * is;
                     sh = p.bn_beta[c] - (float)m * sc;
                     if (tm == 0) {
                         p.bn_vec[c] = (float)m;
@@ -683,11 +687,10 @@ int pipe_launch(const IgemmParams& p0, hipStream_t s) {
     p.ntiles = (p.OC + BN - 1) / BN;
     constexpr int smem = NST * (BM + BN) * 128 + BM * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;      // bit d: set for HIP device d
+    if (cy_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_pipe_kernel<T, BM, BN, WN, NST, EPI_LDS, LOADERS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     if (p.flags & CY_CONV_BN_FUSED) {
         // the two-phase epilogue waits for the whole grid: every block must be resident at once

@@ -529,11 +529,10 @@ __global__ void __launch_bounds__(64 * NCW + 256 * LD, NCW == 8 ? 3 : (LD ? 4 : 
 template <typename T, int BCO, int BCI, int LD = 0, int BKP = 64, int NST = 2, int NCW = 4>
 int launch_dma(const WgradParams& p, int split, hipStream_t s) {
     constexpr int smem = NST * BKP * (BCO * 2 + BCI * 2);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;      // bit d: set for HIP device d
+    if (cy_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, BCO, BCI, LD, BKP, NST, NCW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     WgradParams q = p;
     q.ncol_tiles = (p.Ncols + BCI - 1) / BCI;
@@ -547,11 +546,10 @@ template <typename T, int BCO, int BCI, bool USE_TR>
 int launch(const WgradParams& p, int split, hipStream_t s) {
     constexpr int BKP = WTraits<T>::BKP;
     constexpr int smem = 2 * BKP * (BCO * (int)sizeof(T) + 32 + BCI * (int)sizeof(T) + 32);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;      // bit d: set for HIP device d
+    if (cy_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, USE_TR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     WgradParams q = p;
     q.ncol_tiles = (p.Ncols + BCI - 1) / BCI;

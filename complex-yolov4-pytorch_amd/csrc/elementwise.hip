@@ -1315,15 +1315,14 @@ extern "C" int cy_pack_weights_multi(const cy_pack_desc* desc, const int32_t* bl
     CY_ENTER();
     if (!desc || !blocks || nblocks < 1) return CY_ERR_ARG;
     // LDS for the largest tile (3x3 taps): 64 rows x (9 * 64 + one 16-byte chunk) elements (75 KB f16 / 148 KB f32)
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;      // bit d: set for HIP device d
+    if (cy_first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_weights_multi_kernel<f16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (9 * 64 + 8) * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_weights_multi_kernel<bf16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (9 * 64 + 8) * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_weights_multi_kernel<float>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (9 * 64 + 4) * 4);
-        attr_done = true;
     }
     if (dtype == CY_F16)
         hipLaunchKernelGGL((pack_weights_multi_kernel<f16>), dim3(nblocks), dim3(256), 64 * (9 * 64 + 8) * 2, cy_s(s), desc, blocks);

@@ -38,13 +38,12 @@ __device__ __forceinline__ void corners(float x, float y, float w, float l, floa
 // ---- lane-private work arrays in LDS --------------------------------------------------------------------------------
 // The polygon routines below index small per-lane arrays with data-dependent indices (vertex lists that grow and shrink).
 // As register arrays hipcc serves such an index through the VGPR-index mode (s_set_gpr_idx_on ... s_set_gpr_idx_off), as
-// stack arrays through scratch memory; kernels of BOTH kinds returned different results in 0.2-2 % of launches whenever
-// another kernel ran beside them on a second HIP stream and were exact when alone (tools/head_race_probe2.py: whole groups of
-// 8-16 lanes of one wave with a wrong clip or hull, the rest of the launch untouched; round 2 saw the scratch flavour).  The
-// common factor is wave state that only matters while such a region executes and the queues are being time-shared; whatever
-// the mechanism underneath, the routines no longer depend on it: every dynamically indexed array lives in LDS, element i of
-// lane l at word (slot * 16 + i) * 64 + l (conflict-free, a data-dependent index is plain address arithmetic), and what
-// stays in registers is only ever indexed by unrolled loop counters.  32 KB per 64-thread block; doubles pair two slots.
+// stack arrays through scratch memory; here every dynamically indexed array lives in LDS, element i of lane l at word
+// (slot * 16 + i) * 64 + l (conflict-free, a data-dependent index is plain address arithmetic), and what stays in registers is
+// only ever indexed by unrolled loop counters: no private segment, no index mode.  32 KB per 64-thread block; doubles pair
+// two slots.  (Rounds 2-3 moved the arrays here while hunting results that changed in lanes 48-63 of a wave whenever another
+// kernel ran beside these ones.  The storage was not the cause: the SLP-packed float32 arithmetic was -- see build.py
+// (-fno-slp-vectorize for this code) and profiles/r05_head_race.txt.)
 constexpr int POOL_LANES = 64, POOL_SLOTS = 8, POOL_LEN = 16;
 constexpr int POOL_BYTES = POOL_SLOTS * POOL_LEN * POOL_LANES * 4;
 struct Pool {

@@ -83,11 +83,21 @@ __global__ void decode3_kernel(HeadP h0, HeadP h1, HeadP h2, int B, int A, int C
 // over the 4 lanes by __shfl_xor with the reference's tie rule (the FIRST maximum in anchor order).  Every lane raises the
 // "not no-object" flags of its own anchors; lane 0 of the target records the assignment and claims the cell.
 // (64-thread blocks, stated to the compiler: with the register budget of a single wave per SIMD the polygon arrays of the
-// per-target kernels are promoted to registers.  They were the only kernels of the step with scratch memory -- 368 and 880
-// bytes per lane -- and the ones whose results changed when another kernel ran beside them: tools/head_race_probe.py)
+// per-target kernels need no scratch memory.)
 constexpr int LPT = 4;
-__device__ __forceinline__ void assign_body(const geom::Pool& P, const float* __restrict__ targets, int nT, int B, int G, int A,
-                                            const Anchors& an, float ignore_thresh, const Work& w) {
+
+// Number of live target rows of a launch.  ncap: the count the launch was SIZED for (grid, workspace layout); nT_dev: optional
+// device word holding the batch's real count (<= ncap).  With it one recorded launch list (cy_run_plan) serves every batch whose
+// count falls into the same bucket -- KITTI batches differ in their number of boxes almost every step -- and rows
+// [count, ncap) of the target buffer are never looked at.
+__device__ __forceinline__ int live_rows(int ncap, const int* __restrict__ nT_dev) {
+    if (!nT_dev) return ncap;
+    const int n = *nT_dev;
+    return n < 0 ? 0 : (n > ncap ? ncap : n);
+}
+__device__ __forceinline__ void assign_body(const geom::Pool& P, const float* __restrict__ targets, int ncap, const int* __restrict__ nT_dev,
+                                            int B, int G, int A, const Anchors& an, float ignore_thresh, const Work& w) {
+    const int nT = live_rows(ncap, nT_dev);
     const int lane = threadIdx.x, sub = lane & (LPT - 1);
     const int k = blockIdx.x * (64 / LPT) + (lane >> 2);
     const bool live = k < nT;
@@ -149,12 +159,12 @@ __device__ __forceinline__ void assign_body(const geom::Pool& P, const float* __
 __global__ void __launch_bounds__(64) assign_kernel(const float* __restrict__ targets, int nT, int B, int G, int A, Anchors an,
                                                     float ignore_thresh, Work w) {
     CY_GEOM_POOL(P);
-    assign_body(P, targets, nT, B, G, A, an, ignore_thresh, w);
+    assign_body(P, targets, nT, nullptr, B, G, A, an, ignore_thresh, w);
 }
-__global__ void __launch_bounds__(64) assign3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int nT, int B, int A,
-                                                     float ignore_thresh) {
+__global__ void __launch_bounds__(64) assign3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int ncap,
+                                                     const int* __restrict__ nT_dev, int B, int A, float ignore_thresh) {
     CY_GEOM_POOL(P);
-    CY_HEAD_SWITCH(assign_body(P, targets, nT, B, h.G, A, h.an, ignore_thresh, h.w))
+    CY_HEAD_SWITCH(assign_body(P, targets, ncap, nT_dev, B, h.G, A, h.an, ignore_thresh, h.w))
 }
 
 __device__ __forceinline__ void decode_box(const float* t, int gi, int gj, float aw, float ah, float* box) {
@@ -172,11 +182,11 @@ __device__ __forceinline__ void decode_box(const float* t, int gi, int gj, float
 // one lane per target each, every wave executing a single code path (two lanes of a wave would run the halves one after the
 // other: divergence serialises them) -- and leave their results in the workspace; pairs_finish_kernel joins them.
 template <bool GIOU>
-__device__ __forceinline__ void pairs_body(const geom::Pool& P, const float* __restrict__ logits, const float* __restrict__ targets, int nT,
-                                           int G, int A, int C, const Anchors& an, const Work& w, int nb) {
+__device__ __forceinline__ void pairs_body(const geom::Pool& P, const float* __restrict__ logits, const float* __restrict__ targets, int ncap,
+                                           const int* __restrict__ nT_dev, int G, int A, int C, const Anchors& an, const Work& w, int nb) {
     const int part = (int)blockIdx.x >= nb ? 1 : 0;
     const int k = ((int)blockIdx.x - part * nb) * 64 + (int)threadIdx.x;
-    if (k >= nT) return;
+    if (k >= live_rows(ncap, nT_dev)) return;
     const int b = w.ti[k * 4];
     if (b < 0) return;
     const int a = w.ti[k * 4 + 1], gj = w.ti[k * 4 + 2], gi = w.ti[k * 4 + 3];
@@ -190,7 +200,7 @@ __device__ __forceinline__ void pairs_body(const geom::Pool& P, const float* __r
     float pcx[4], pcy[4], tcx[4], tcy[4];
     geom::corners(pb[0], pb[1], pb[2], pb[3], atan2f(pb[4], pb[5]), pcx, pcy);
     geom::corners(tb[0], tb[1], tb[2], tb[3], atan2f(tb[4], tb[5]), tcx, tcy);
-    float* out = w.part + ((long)part * nT + k) * 12;
+    float* out = w.part + ((long)part * ncap + k) * 12;      // (the two halves are ncap rows apart: the layout follows the capacity)
     if (part == 0) {
         const geom::InterPart ip = geom::inter_part<GIOU>(P, pcx, pcy, tcx, tcy);
         out[0] = ip.inter;
@@ -209,19 +219,20 @@ template <bool GIOU>
 __global__ void __launch_bounds__(64) pairs_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
                                                    int G, int A, int C, Anchors an, Work w, int nb) {
     CY_GEOM_POOL(P);
-    pairs_body<GIOU>(P, logits, targets, nT, G, A, C, an, w, nb);
+    pairs_body<GIOU>(P, logits, targets, nT, nullptr, G, A, C, an, w, nb);
 }
 template <bool GIOU>
-__global__ void __launch_bounds__(64) pairs3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int nT, int A, int C, int nb) {
+__global__ void __launch_bounds__(64) pairs3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int ncap,
+                                                    const int* __restrict__ nT_dev, int A, int C, int nb) {
     CY_GEOM_POOL(P);
-    CY_HEAD_SWITCH(pairs_body<GIOU>(P, h.logits, targets, nT, h.G, A, C, h.an, h.w, nb))
+    CY_HEAD_SWITCH(pairs_body<GIOU>(P, h.logits, targets, ncap, nT_dev, h.G, A, C, h.an, h.w, nb))
 }
 
 template <bool GIOU>
-__device__ __forceinline__ void pairs_finish_body(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
-                                                  int G, int A, int C, const Anchors& an, const Work& w) {
+__device__ __forceinline__ void pairs_finish_body(const float* __restrict__ logits, const float* __restrict__ targets, int ncap,
+                                                  const int* __restrict__ nT_dev, int G, int A, int C, const Anchors& an, const Work& w) {
     const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= nT) return;
+    if (k >= live_rows(ncap, nT_dev)) return;
     const int b = w.ti[k * 4];
     float* tf = w.tf + (long)k * 8;
     if (b < 0) {
@@ -239,7 +250,7 @@ __device__ __forceinline__ void pairs_finish_body(const float* __restrict__ logi
     geom::InterPart ip;
     geom::HullPart hp;
     const float* pi = w.part + (long)k * 12;
-    const float* ph = w.part + ((long)nT + k) * 12;
+    const float* ph = w.part + ((long)ncap + k) * 12;
     ip.inter = pi[0];
     hp.carea = GIOU ? ph[0] : 0.f; hp.sg = GIOU ? ph[1] : 0.f; hp.on = GIOU ? __float_as_int(ph[10]) : 0;
 #pragma unroll
@@ -257,11 +268,12 @@ __device__ __forceinline__ void pairs_finish_body(const float* __restrict__ logi
 template <bool GIOU>
 __global__ void __launch_bounds__(64) pairs_finish_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int nT,
                                                           int G, int A, int C, Anchors an, Work w) {
-    pairs_finish_body<GIOU>(logits, targets, nT, G, A, C, an, w);
+    pairs_finish_body<GIOU>(logits, targets, nT, nullptr, G, A, C, an, w);
 }
 template <bool GIOU>
-__global__ void __launch_bounds__(64) pairs_finish3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int nT, int A, int C) {
-    CY_HEAD_SWITCH(pairs_finish_body<GIOU>(h.logits, targets, nT, h.G, A, C, h.an, h.w))
+__global__ void __launch_bounds__(64) pairs_finish3_kernel(HeadP h0, HeadP h1, HeadP h2, const float* __restrict__ targets, int ncap,
+                                                           const int* __restrict__ nT_dev, int A, int C) {
+    CY_HEAD_SWITCH(pairs_finish_body<GIOU>(h.logits, targets, ncap, nT_dev, h.G, A, C, h.an, h.w))
 }
 
 __device__ __forceinline__ float bce_grad(float p, float t) {
@@ -379,8 +391,11 @@ __global__ void __launch_bounds__(256) dense3_kernel(HeadP h0, HeadP h1, HeadP h
 // order, and with it the last bits of d(logits), depended on what else ran on the GPU) the FIRST target of a cell sums the
 // contributions of all its targets in index order and is the only writer.  The search for a cell's targets is wave-wide: 64
 // candidates per __ballot instead of one dependent global load per candidate (28 us of latency per head with nT = 96).
-__device__ __forceinline__ void giou_grad_body(const float* __restrict__ logits, int nT, int G, int A, int C, const Anchors& an, float coef,
-                                               const Work& w, float* dlogits) {
+__device__ __forceinline__ void giou_grad_body(const float* __restrict__ logits, int ncap, const int* __restrict__ nT_dev, int G, int A, int C,
+                                               const Anchors& an, float lgiou, const Work& w, float* dlogits) {
+    const int nT = live_rows(ncap, nT_dev);
+    if (nT <= 0) return;
+    const float coef = lgiou / (float)nT;      // d(mean GIoU term x its loss weight) / d term: the float32 division the host used to do
     const int lane = threadIdx.x;
     const int k = blockIdx.x * 64 + lane;
     const bool live = k < nT;
@@ -429,20 +444,23 @@ __device__ __forceinline__ void giou_grad_body(const float* __restrict__ logits,
         for (int i = 0; i < 6; ++i) dlogits[base + i] += s[i];
     }
 }
-__global__ void __launch_bounds__(64) giou_grad_kernel(const float* __restrict__ logits, int nT, int G, int A, int C, Anchors an, float coef,
+__global__ void __launch_bounds__(64) giou_grad_kernel(const float* __restrict__ logits, int nT, int G, int A, int C, Anchors an, float lgiou,
                                                        Work w, float* dlogits) {
-    giou_grad_body(logits, nT, G, A, C, an, coef, w, dlogits);
+    giou_grad_body(logits, nT, nullptr, G, A, C, an, lgiou, w, dlogits);
 }
-__global__ void __launch_bounds__(64) giou_grad3_kernel(HeadP h0, HeadP h1, HeadP h2, int nT, int A, int C, float coef) {
-    CY_HEAD_SWITCH(giou_grad_body(h.logits, nT, h.G, A, C, h.an, coef, h.w, h.dlogits))
+__global__ void __launch_bounds__(64) giou_grad3_kernel(HeadP h0, HeadP h1, HeadP h2, int ncap, const int* __restrict__ nT_dev, int A, int C,
+                                                        float lgiou) {
+    CY_HEAD_SWITCH(giou_grad_body(h.logits, ncap, nT_dev, h.G, A, C, h.an, lgiou, h.w, h.dlogits))
 }
 
 struct LossScales {
     float noobj, obj, lgiou, leular, lobj, lcls;
 };
 
-__device__ __forceinline__ void finalize_body(const Work& w, long cells, int nT, int C, int use_giou, const LossScales& ls, float* metrics) {
+__device__ __forceinline__ void finalize_body(const Work& w, long cells, int ncap, const int* __restrict__ nT_dev, int C, int use_giou,
+                                              const LossScales& ls, float* metrics) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int nT = live_rows(ncap, nT_dev);
     const double nObj = (double)w.cnt[C_NOBJ];
     const double nNo = (double)(cells - w.cnt[C_NCLEARED]);
     const double* a = w.acc;
@@ -477,10 +495,10 @@ __device__ __forceinline__ void finalize_body(const Work& w, long cells, int nT,
     metrics[19] = (float)w.cnt[C_ERR];
 }
 __global__ void finalize_kernel(Work w, long cells, int nT, int C, int use_giou, LossScales ls, float* metrics) {
-    finalize_body(w, cells, nT, C, use_giou, ls, metrics);
+    finalize_body(w, cells, nT, nullptr, C, use_giou, ls, metrics);
 }
-__global__ void finalize3_kernel(HeadP h0, HeadP h1, HeadP h2, int nT, int C, int use_giou, LossScales ls) {
-    CY_HEAD_SWITCH(finalize_body(h.w, h.cells, nT, C, use_giou, ls, h.metrics))
+__global__ void finalize3_kernel(HeadP h0, HeadP h1, HeadP h2, int ncap, const int* __restrict__ nT_dev, int C, int use_giou, LossScales ls) {
+    CY_HEAD_SWITCH(finalize_body(h.w, h.cells, ncap, nT_dev, C, use_giou, ls, h.metrics))
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -529,11 +547,9 @@ extern "C" int cy_yolo_decode(const float* logits, int B, int G, int A, int C, c
     return 0;
 }
 
-// Scratch (private-segment) bytes per lane of the per-target kernels, as the loaded code object reports them.  They must be
-// 0 for the heads to run on a side stream (models/engine.py): with their polygon arrays in scratch, assign / pairs returned
-// different owners and IoUs in ~1 % of launches whenever another kernel ran beside them (tools/head_race_probe.py; root cause
-// not found -- nothing reads an uninitialised or out-of-range array element, the suspects left are the runtime's per-queue
-// scratch provisioning under concurrent dispatch).  build.py checks the same figure at compile time.
+// Scratch (private-segment) bytes per lane of the per-target kernels, as the loaded code object reports them: 0 by
+// construction (geometry.hpp keeps every dynamically indexed array in LDS) and by build.py's check; the engine still asks
+// before it lets the heads run beside other kernels (CY_HEADS_SIDE=1).
 extern "C" int cy_head_scratch_bytes(void) {
     CY_ENTER();
     const void* fns[] = {(const void*)assign_kernel, (const void*)pairs_kernel<true>, (const void*)pairs_kernel<false>,
@@ -590,10 +606,10 @@ extern "C" int64_t cy_yolo_loss_multi_workspace(int nheads, const int* Gs_host, 
 // The heads are a chain of one-wave kernels that is pure latency (~0.1 ms per head); since round 3 they run on the trunk's stream
 // (profiles/r03_head_race.txt), where that latency is on the critical path.  Same kernels bodies, same arithmetic and the same
 // results as cy_yolo_decode + cy_yolo_loss per head.
-extern "C" int cy_yolo_loss_multi(int nheads, const cy_head_in* heads_host, int B, int A, int C, const float* targets, int nT,
-                                  float img_size, float ignore_thresh, int use_giou, void* workspace, float* out, int rows_total,
-                                  cy_stream_t s) {
-    CY_ENTER();
+static int yolo_loss_multi_impl(int nheads, const cy_head_in* heads_host, int B, int A, int C, const float* targets, int nT,
+                                const int32_t* nT_dev, float img_size, float ignore_thresh, int use_giou, void* workspace, float* out,
+                                int rows_total, cy_stream_t s) {
+    // nT: the row count the launches are sized for; nT_dev (optional): the live count on the device, <= nT
     if (nheads < 1 || nheads > 3 || !heads_host || !workspace || nT < 0 || (nT > 0 && !targets)) return CY_ERR_ARG;
     if (C < 1 || C > 23 || 7 + C > 32 || A < 1 || A > MAXA) return CY_ERR_ARG;
     HeadP hp[3];
@@ -638,22 +654,39 @@ extern "C" int cy_yolo_loss_multi(int nheads, const cy_head_in* heads_host, int 
     const int tb = (nT + 63) / 64;
     if (nT > 0) {
         const int ta = (nT + 64 / LPT - 1) / (64 / LPT);
-        hipLaunchKernelGGL(assign3_kernel, dim3(ta, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, B, A, ignore_thresh);
+        hipLaunchKernelGGL(assign3_kernel, dim3(ta, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, nT_dev, B, A, ignore_thresh);
         if (use_giou) {
-            hipLaunchKernelGGL(pairs3_kernel<true>, dim3(2 * tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, A, C, tb);
-            hipLaunchKernelGGL(pairs_finish3_kernel<true>, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, A, C);
+            hipLaunchKernelGGL(pairs3_kernel<true>, dim3(2 * tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, nT_dev, A, C, tb);
+            hipLaunchKernelGGL(pairs_finish3_kernel<true>, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, nT_dev, A, C);
         } else {
-            hipLaunchKernelGGL(pairs3_kernel<false>, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, A, C, tb);
-            hipLaunchKernelGGL(pairs_finish3_kernel<false>, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, A, C);
+            hipLaunchKernelGGL(pairs3_kernel<false>, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, nT_dev, A, C, tb);
+            hipLaunchKernelGGL(pairs_finish3_kernel<false>, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], targets, nT, nT_dev, A, C);
         }
     }
     const int grid = (int)((max_cells + 255) / 256 > 2048 ? 2048 : (max_cells + 255) / 256);
     hipLaunchKernelGGL(dense3_kernel, dim3(grid, nheads), dim3(256), 0, cy_s(s), hp[0], hp[1], hp[2], targets, B, A, C, sc);
     if (nT > 0 && use_giou)
-        hipLaunchKernelGGL(giou_grad3_kernel, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], nT, A, C, ls.lgiou / (float)nT);
-    hipLaunchKernelGGL(finalize3_kernel, gy, dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], nT, C, use_giou, ls);
+        hipLaunchKernelGGL(giou_grad3_kernel, dim3(tb, nheads), dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], nT, nT_dev, A, C, ls.lgiou);
+    hipLaunchKernelGGL(finalize3_kernel, gy, dim3(64), 0, cy_s(s), hp[0], hp[1], hp[2], nT, nT_dev, C, use_giou, ls);
     CY_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cy_yolo_loss_multi(int nheads, const cy_head_in* heads_host, int B, int A, int C, const float* targets, int nT,
+                                  float img_size, float ignore_thresh, int use_giou, void* workspace, float* out, int rows_total,
+                                  cy_stream_t s) {
+    CY_ENTER();
+    return yolo_loss_multi_impl(nheads, heads_host, B, A, C, targets, nT, nullptr, img_size, ignore_thresh, use_giou, workspace, out,
+                                rows_total, s);
+}
+
+extern "C" int cy_yolo_loss_multi_n(int nheads, const cy_head_in* heads_host, int B, int A, int C, const float* targets, int nT_cap,
+                                    const int32_t* nT_dev, float img_size, float ignore_thresh, int use_giou, void* workspace,
+                                    float* out, int rows_total, cy_stream_t s) {
+    CY_ENTER();
+    if (!nT_dev || nT_cap < 1 || !targets) return CY_ERR_ARG;
+    return yolo_loss_multi_impl(nheads, heads_host, B, A, C, targets, nT_cap, nT_dev, img_size, ignore_thresh, use_giou, workspace, out,
+                                rows_total, s);
 }
 
 extern "C" int cy_yolo_loss(const float* logits, int B, int G, int A, int C, const float* targets, int nT,
@@ -694,8 +727,7 @@ extern "C" int cy_yolo_loss(const float* logits, int B, int G, int A, int C, con
     const int grid = (int)((cells + 255) / 256 > 2048 ? 2048 : (cells + 255) / 256);
     hipLaunchKernelGGL(dense_kernel, dim3(grid), dim3(256), 0, cy_s(s), logits, targets, B, G, A, C, an, sc, w, dlogits);
     if (nT > 0 && use_giou)
-        hipLaunchKernelGGL(giou_grad_kernel, dim3(tb), dim3(64), 0, cy_s(s), logits, nT, G, A, C, an,
-                           ls.lgiou / (float)nT, w, dlogits);
+        hipLaunchKernelGGL(giou_grad_kernel, dim3(tb), dim3(64), 0, cy_s(s), logits, nT, G, A, C, an, ls.lgiou, w, dlogits);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, cy_s(s), w, cells, nT, C, use_giou, ls, metrics);
     CY_LAUNCH_CHECK();
     return 0;

@@ -191,8 +191,10 @@ class Engine:
                        and hasattr(ops, 'start_recording') and os.environ.get('CY_HEADS_SIDE', '0') != '1')
         self._fwd_progs, self._bwd_progs, self._fwd_key = {}, {}, None
         self.replayed = 0                        # passes issued through cy_run_plan (tests / probes)
+        self.passes = 0                          # forward + backward passes issued in all (replayed / passes = the hit rate)
         self._on_module_done = None
         self._tg_buf = None                      # engine-owned copy of the target rows (a recorded list needs a fixed address)
+        self._nt_dev = None                      # int32 device word: this batch's number of target rows
         self._gout_buf = new('gout', 1, torch.float32, zero=True) if training else None
         self.fwd_serial = 0
         self._reduce_groups = None
@@ -275,6 +277,7 @@ class Engine:
     def forward(self, x, targets, params, use_giou, img_size, weights_epoch=None):
         plan = self.plan
         self.fwd_serial += 1
+        self.passes += 1
         self._pending_heads = []          # (a forward that raised after queueing a head must not leak it into this one)
         if self.stats_pair is not None and self.training:
             # the alternating statistics tables restart from a defined state every pass (complex_yolov4.cfg has an ODD number of
@@ -322,23 +325,35 @@ class Engine:
             self._heads_on_side = False
         return self.outputs
 
-    MAX_PROGRAMS = 64        # recorded launch lists kept per direction (one per target-row count seen: ~150 KB of host memory each)
+    MAX_PROGRAMS = 64        # recorded launch lists kept per direction (one per 64-row bucket of the target count, loss scale, ...: ~150 KB each)
 
     def _remember(self, table, key, prog):
         if len(table) >= self.MAX_PROGRAMS:      # (KITTI batches differ in their number of boxes: oldest recordings go first)
             table.pop(next(iter(table)))
         table[key] = prog
 
+    @staticmethod
+    def _rows_bucket(nT):
+        """Row capacity the head launches are sized for: the batch's count rounded up to a multiple of 64 (one wave of targets)."""
+        return max(64, (int(nT) + 63) // 64 * 64)
+
     def _own_targets(self, targets):
-        """The caller's target rows copied into an engine-owned buffer (a recorded launch list needs them at a fixed address);
-        -> the view of that buffer holding this batch's rows."""
+        """The caller's target rows copied into an engine-owned buffer (a recorded launch list needs them at a fixed address)
+        and their count into a device word (``_nt_dev``): the batched heads (cy_yolo_loss_multi_n) are sized for the count's
+        64-row bucket and read the live count on the device, so ONE recorded pass serves every batch of the bucket -- the
+        reference's dataloader yields a different number of boxes almost every step.  -> the view of the buffer
+        holding this batch's rows."""
         if targets is None:
             return None
         nT = int(targets.shape[0])
-        if self._tg_buf is None or self._tg_buf.shape[0] < max(nT, 1) or self._tg_buf.shape[1] != targets.shape[1]:
+        cap = self._rows_bucket(nT)
+        if self._tg_buf is None or self._tg_buf.shape[0] < cap or self._tg_buf.shape[1] != targets.shape[1]:
             if self._tg_buf is not None:
                 self._retired_ws.append(self._tg_buf)
-            self._tg_buf = self.arena.new('targets', (max(2 * nT, 256), targets.shape[1]), torch.float32, zero=True)
+            self._tg_buf = self.arena.new('targets', (2 * cap, targets.shape[1]), torch.float32, zero=True)
+        if self._nt_dev is None:
+            self._nt_dev = self.arena.new('live target rows', 1, torch.int32, zero=True)
+        self._nt_dev.fill_(nT)          # (the scalar travels in the fill's kernel arguments: no host buffer to race with)
         own = self._tg_buf[:nT]
         if nT:
             own.copy_(targets, non_blocking=True)
@@ -351,7 +366,9 @@ class Engine:
         moves tensors, and a replay would keep writing running statistics through the stale address -- ADVICE r4), loss
         variant, image size, stream.  One tuple of ~540 integers per forward: ~60 us."""
         pk = tuple(t.data_ptr() for t in params.values())
-        return (None if targets is None else (int(targets.shape[0]), targets.data_ptr()), bool(use_giou), int(img_size), pk,
+        rows = int(targets.shape[0]) if targets is not None else 0
+        return (None if targets is None else ((self._rows_bucket(rows), 'bucket') if self._multi_heads else (rows, 'exact'), targets.data_ptr()),
+                bool(use_giou), int(img_size), pk,
                 torch.cuda.current_stream(self.device).cuda_stream, None if self.training else weights_epoch)
 
     def _pack_all(self, weights_epoch=None):
@@ -532,15 +549,13 @@ class Engine:
     def _f_yolo(self, rec, targets, use_giou, img_size):
         if (self.side is not None and targets is not None and not self._in_side_head
                 and os.environ.get('CY_HEADS_SIDE', '0') == '1' and self._heads_side_ok()):
-            # OPT-IN (CY_HEADS_SIDE=1; default off since round 3).  The decode + loss kernels of a head are a dozen one-wave
-            # launches, ~0.1 ms of latency that nothing downstream needs before the loss is read; on the side stream they hide
-            # beside the trunk convs that follow the head (+1 %).  But the GIoU kernels are NOT reproducible beside two of our
-            # conv instantiations: tools/head_race_probe2.py shows 0.2-2.5 % of launches with a wrong clip / hull in lanes 48-63 of
-            # a wave whenever igemm_fast<192,128> or the pipelined 384 x 128 tile runs on another stream -- never beside torch
-            # GEMMs, elementwise kernels, BN passes, weight-gradient kernels or the lower-register conv tiles, never alone, and
-            # no other kernel of the step is disturbed (tools/victim_probe.py).  Scratch memory (round 2's suspect), the
-            # VGPR-index mode and uninitialised registers / LDS are ruled out (profiles/r03_head_race.txt); the mechanism is
-            # not found.  Until it is, the heads run where nothing runs beside them.
+            # OPT-IN (CY_HEADS_SIDE=1).  The decode + loss kernels of a head are a dozen one-wave launches, ~0.1 ms of latency that
+            # nothing downstream needs before the loss is read; on the side stream they hide beside the trunk convs that follow
+            # the head (+1 % in round 2, per-head launches).  Rounds 2-4 kept them off it because their results changed in lanes
+            # 48-63 beside two conv instantiations; round 5 found the cause (SLP-packed float32 arithmetic beside MFMA waves,
+            # profiles/r05_head_race.txt) and removed it at build time, so the option is safe again -- it stays an option because
+            # the batched three-heads-in-one-sequence form (cy_yolo_loss_multi) runs at the LAST head, where no trunk conv is left
+            # to hide behind, and because this path is issued through torch events (not part of a recorded launch list).
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self.side.wait_event(ev)
@@ -580,10 +595,10 @@ class Engine:
     def _run_heads(self, targets, use_giou, img_size):
         recs, self._pending_heads = self._pending_heads, []
         r0 = recs[0]
-        nT = targets.shape[0]
-        if self._head_table is None or self._head_table[2] < nT:
-            cap = max(nT, 64) if self._head_table is None else max(nT, 2 * self._head_table[2])     # room to grow: KITTI batches vary
-            need = ops.yolo_loss_multi_workspace([r['G'] for r in recs], self.N, r0['A'], r0['C'], cap)
+        cap = self._rows_bucket(targets.shape[0])
+        if self._head_table is None or self._head_table[2] < cap:
+            wcap = cap if self._head_table is None else max(cap, 2 * self._head_table[2])     # room to grow: KITTI batches vary
+            need = ops.yolo_loss_multi_workspace([r['G'] for r in recs], self.N, r0['A'], r0['C'], wcap)
             if self._head_table is not None:
                 self._retired_ws.append(self._head_table)      # (table and workspace: see __init__)
             ws = self.arena.new('heads workspace', need, torch.uint8)
@@ -593,10 +608,11 @@ class Engine:
                 if self.dlogits[h] is None:
                     self.dlogits[h] = self.arena.new('dlogits[%d]' % h, self.act[r['logits'].st.sid].numel(), torch.float32)
                 heads.append((self.act[r['logits'].st.sid], self.dlogits[h], self.metrics[h], r['anchors'], r['G'], r['row_offset']))
-            self._head_table = (ops.make_head_table(heads), ws, cap)
+            self._head_table = (ops.make_head_table(heads), ws, wcap)
         table, ws, _ = self._head_table
-        ops.yolo_loss_multi(table, len(recs), self.N, r0['A'], r0['C'], targets, img_size, r0['ignore_thresh'], use_giou, ws,
-                            self.outputs, self.plan.rows_total)
+        # sized for the bucket, live count on the device (the workspace layout follows the capacity PASSED, not the allocated one)
+        ops.yolo_loss_multi(table, len(recs), self.N, r0['A'], r0['C'], self._tg_buf, img_size, r0['ignore_thresh'], use_giou, ws,
+                            self.outputs, self.plan.rows_total, cap=cap, nt_dev=self._nt_dev)
 
     def check_grid_waits(self):
         """Raise if a two-phase launch (ops.conv_bn_act_train) ever gave up waiting for its grid (ticket[2]): its outputs were
@@ -611,6 +627,7 @@ class Engine:
         ``loss_scale`` (= act_scale, or act_scale * world so that a plain SUM all-reduce yields the mean).
         on_module_done(idx) is called after the kernels that finish module idx's parameter gradients are queued."""
         assert self.training
+        self.passes += 1
         self.grads, self.ls = grads, float(loss_scale)
         self._gout_buf.copy_(gout_dev.reshape(-1)[:1], non_blocking=True)      # fixed address for the recorded list
         self.gout = self._gout_buf

@@ -638,8 +638,14 @@ def make_head_table(heads):
     return arr, keep
 
 
-def yolo_loss_multi(table, nheads, B, A, C, targets, img_size, ignore_thresh, use_giou, workspace, out, rows_total):
-    """Decode (out is not None) + loss of all heads in one sequence of launches (cy_yolo_loss_multi)."""
+def yolo_loss_multi(table, nheads, B, A, C, targets, img_size, ignore_thresh, use_giou, workspace, out, rows_total, cap=None, nt_dev=None):
+    """Decode (out is not None) + loss of all heads in one sequence of launches (cy_yolo_loss_multi).  With ``cap`` / ``nt_dev``
+    (cy_yolo_loss_multi_n): ``targets`` is a buffer of at least ``cap`` rows, the int32 device word ``nt_dev`` holds how many of
+    them are this batch's."""
+    if nt_dev is not None:
+        lib().call('cy_yolo_loss_multi_n', nheads, ctypes.cast(table[0], ctypes.c_void_p), B, A, C, _p(targets), int(cap), _p(nt_dev),
+                   float(img_size), float(ignore_thresh), int(bool(use_giou)), _p(workspace), _p(out), rows_total, _stream())
+        return
     nT = 0 if targets is None else targets.shape[0]
     lib().call('cy_yolo_loss_multi', nheads, ctypes.cast(table[0], ctypes.c_void_p), B, A, C, _p(targets) if nT else None, nT,
                float(img_size), float(ignore_thresh), int(bool(use_giou)), _p(workspace), _p(out), rows_total, _stream())

@@ -427,8 +427,9 @@ def test_model_forward_with_two_phase_convs_matches_the_separate_passes(monkeypa
 def test_replayed_launch_lists_equal_eager_steps(monkeypatch):
     """the passes of a step re-issued from C (ops.start_recording -> cy_run_plan) against the same steps
     issued call by call from Python, deterministic mode: losses, parameters and BatchNorm running statistics bit-identical over
-    nine Adam steps with three target-row counts (a new count records a new list; a count seen before replays its old one, also
-    after the head workspace has grown in between) and a learning-rate change."""
+    nine Adam steps with three target-row counts in TWO 64-row buckets (the batched heads read the live count on the device,
+    cy_yolo_loss_multi_n: a new bucket records a new list, every count of a bucket seen before replays it -- also after the head
+    workspace has grown in between) and a learning-rate change."""
     from complex_yolov4_pytorch_amd.optim import FusedAdam
     S = 416
     mk = lambda seed, per: (syn.bev_images(2, S, seed=seed).to(DEV), syn.targets(2, per, S, seed=seed).to(DEV))
@@ -456,9 +457,10 @@ def test_replayed_launch_lists_equal_eager_steps(monkeypatch):
         model.release_engines()
         del opt, model
     assert runs['eager'][2] == 0 and runs['eager'][3] == (0, 0)
-    # step 1 tunes, step 2 records (12 rows), step 3 replays, step 4 records (10 rows), 5 replays 12, 6 records 80, 7-9 replay
-    assert runs['replay'][3] == (3, 3), runs['replay'][3]
-    assert runs['replay'][2] == 2 * 5, runs['replay'][2]
+    # step 1 tunes, step 2 records (12 rows: bucket 64), 3 replays, 4 REPLAYS with 10 rows, 5 replays, 6 records (80 rows: bucket 128),
+    # 7-9 replay
+    assert runs['replay'][3] == (2, 2), runs['replay'][3]
+    assert runs['replay'][2] == 2 * 6, runs['replay'][2]
     assert runs['replay'][0] == runs['eager'][0], (runs['replay'][0], runs['eager'][0])
     for k, v in runs['eager'][1].items():
         assert torch.equal(v, runs['replay'][1][k]), k
