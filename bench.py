@@ -97,7 +97,8 @@ def kernel_sources_sha():
     return tune.sources_sha()
 
 
-PMC_FILE = 'profiles/r04_pmc_hbm_traffic.json'
+PMC_FILE = 'profiles/r05_pmc_hbm_traffic.json'
+SQ_FILE = 'profiles/r05_sq_counters.json'
 
 
 def pmc_traffic(kernel, a):
@@ -126,6 +127,26 @@ def pmc_traffic(kernel, a):
                     dispatches_per_step=round(d['launches'] / steps, 1), whole_step_bytes=round(whole), unit='bytes',
                     git_head=doc.get('git_head'), kernel_sources_sha=doc.get('kernel_sources_sha'),
                     source=PMC_FILE + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.sh)')
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def sq_counters(a):
+    """BASELINE's "MFMA utilisation % (rocprof)": the committed SQ-counter passes of this same workload (tools/pmc_sq.sh:
+    SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES) per kernel family, LDS array activity, wave-cycle shares) -- like the PMC
+    traffic only while the kernel sources are the ones it was measured on; a stale file yields a note, never an old number."""
+    if (a.batch, a.size, a.dtype, a.config) != (16, 608, 'f16', 'train608'):
+        return None
+    try:
+        with open(os.path.join(ROOT, SQ_FILE)) as f:
+            doc = json.load(f)
+        if doc.get('kernel_sources_sha') != kernel_sources_sha():
+            return dict(stale=True, measured_on=doc.get('kernel_sources_sha'), now=kernel_sources_sha(), source=SQ_FILE)
+        fam = doc['families']
+        pick = lambda d: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items() if k in ('mfma_busy', 'lds_array_active', 'launches_per_step')}
+        return dict(conv_fwd_dgrad=pick(fam.get('conv fwd/dgrad', {})), wgrad=pick(fam.get('wgrad', {})), whole_step=pick(fam.get('whole step', {})),
+                    definition=doc['definitions']['mfma_busy'], kernel_sources_sha=doc.get('kernel_sources_sha'), git_head=doc.get('git_head'),
+                    source=SQ_FILE + ' (rocprofv3 --pmc SQ_*, tools/pmc_sq.sh; per kernel in the file)')
     except (OSError, KeyError, ValueError):
         return None
 
@@ -549,6 +570,9 @@ def worker(a):
                            achieved=round(f['flops'] / (f['ms_raw'] * 1e-3) / 1e12, 2), unit='TFLOP/s')
                 for name, f in (('conv_only', plain), ('dgrad_with_bn_backward_sums', fused)) if f}
             roofline['by_bound'] = by_bound   # launches above the ridge point against the MFMA peak, the rest against HBM
+            sq = sq_counters(a)
+            roofline['mfma_busy'] = (sq or {}).get('conv_fwd_dgrad', {}).get('mfma_busy') if sq and not sq.get('stale') else None
+            roofline['sq_counters'] = sq      # MFMA pipe busy / LDS activity per family from the committed rocprofv3 SQ passes
             # BASELINE's "MFMA util %": the WHOLE train step's algorithmic FLOPs (forward + input gradient + weight gradient of
             # every conv) over the timed region's wall clock, against the dense MFMA peak
             sf = step_flops(model)

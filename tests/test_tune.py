@@ -71,6 +71,29 @@ def test_pmc_traffic_file_is_stamped_with_the_same_sources(monkeypatch):
     assert 40e9 < step < 80e9            # whole-step HBM traffic of the benchmarked configuration (round 3: 61.5 GB)
 
 
+def test_sq_counter_file_is_stamped_with_the_same_sources(monkeypatch):
+    """BASELINE's "MFMA utilisation % (rocprof)" on the line (roofline.mfma_busy) comes from profiles/r05_sq_counters.json: valid for
+    exactly the kernel sources it was collected on, like the PMC traffic figure."""
+    tune = _fresh_tune(monkeypatch)
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, bench.SQ_FILE)) as f:
+        doc = json.load(f)
+    assert doc['kernel_sources_sha'] == tune.sources_sha(), \
+        '%s was collected on other kernel sources: re-run tools/pmc_sq.sh (bench.py reports mfma_busy: null until then)' % bench.SQ_FILE
+    fam = doc['families']
+    assert {'conv fwd/dgrad', 'wgrad', 'whole step', 'bn_act_fwd', 'bn_bwd_apply'} <= set(fam)
+    assert 0.05 < fam['conv fwd/dgrad']['mfma_busy'] < 0.9 and fam['bn_act_fwd']['mfma_busy'] < 1e-3
+    assert 500 < fam['whole step']['launches_per_step'] < 800
+
+    class A:
+        batch, size, dtype, config = 16, 608, 'f16', 'train608'
+    sq = bench.sq_counters(A)
+    assert sq['conv_fwd_dgrad']['mfma_busy'] == round(fam['conv fwd/dgrad']['mfma_busy'], 4) and 'SQ_VALU_MFMA_BUSY_CYCLES' in sq['definition']
+    A.batch = 8
+    assert bench.sq_counters(A) is None          # any other workload: no figure
+
+
 def test_stale_or_disabled_table_is_ignored(monkeypatch, tmp_path):
     stale = tmp_path / 'stale.json'
     stale.write_text(json.dumps({'kernel_sources_sha': '0' * 16, 'entries': {repr(('fwd', 1)): [7, 0.1]}}))

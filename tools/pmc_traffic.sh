@@ -8,7 +8,7 @@ root=$(pwd)
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$root/gpurun_out/pmc_$c
   rm -rf $out
-  (cd /tmp && rocprofv3 --pmc $c --output-format csv -d $out -- python $root/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra > $root/gpurun_out/pmc_$c.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $c --output-format csv -d $out -- python $root/bench.py --worker --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra > $root/gpurun_out/pmc_$c.log 2>&1)
 done
 python - "$root/gpurun_out" "$root" <<'PY'
 import csv, glob, json, os, sys, collections
@@ -45,7 +45,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         agg[k]['launches'] = max(agg[k]['launches'], v)
 # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-units of 1024? -> the counters are in KB (1 KB = 1024 B) per the tool's derived metric
 out = {'steps_counted': STEADY, 'kernel_sources_sha': bench.kernel_sources_sha(), 'git_head': os.environ.get('GIT_HEAD', 'unknown'),
-       'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra'}
+       'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --worker --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-extra'}
 for k, v in sorted(agg.items()):
     L = max(1, v['launches'])
     out[k] = dict(launches=v['launches'], fetch_bytes_per_launch_corrected=2.0 * 1024.0 * v['FETCH_SIZE'] / L,

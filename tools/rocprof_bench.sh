@@ -11,7 +11,7 @@ run() {   # name steps
   local name=$1 steps=$2
   out=$root/gpurun_out/prof_${tag}_$name
   rm -rf $out
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $root/bench.py --steps $steps --warmup 3 --no-cpu-baseline --no-roofline --no-extra "${extra[@]}" > $root/gpurun_out/prof_${tag}_$name.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $root/bench.py --worker --steps $steps --warmup 3 --no-cpu-baseline --no-roofline --no-extra "${extra[@]}" > $root/gpurun_out/prof_${tag}_$name.log 2>&1)
   cp "$(find $out -name '*kernel_stats.csv' | head -1)" $root/gpurun_out/${tag}_kernel_stats_$name.csv
   find $out -name "*.csv" -size +2M -delete
 }
