@@ -16,6 +16,12 @@ infer32 (configs[3]): model.eval()(imgs) + post_processing_v2 (rotated merge-NMS
 train1024 (configs[4]): the train step at 1024x1024, batch 8.
 The default single-GPU run also measures the other configurations briefly -- each in a fresh process of this same script -- and
 reports them under `other_configs`, so the one driver line carries configs[1], [3], [4] and configs[2]'s per-GPU work.
+
+Process layout (round 5): the command is a SUPERVISOR without a GPU context; everything that touches the GPU runs in a worker
+process (`--worker`, same script).  A GPU memory-access fault kills the process it happens in -- that is how round 4's driver run
+ended with nothing on stdout -- so the supervisor retries a dead worker once (single GPU), maps the fault address onto the
+worker's named device buffers, and ALWAYS prints one JSON line (`fault_retries`, `faults`; `error` if no attempt measured).
+Under a launcher every rank is such a pair; rank 0's supervisor prints the line.  profiles/r05_fault_hunt.txt has the story.
 """
 import argparse
 import json
@@ -28,6 +34,8 @@ import time
 # its own streams the three collide on ONE queue and run serialised (rocprofv3 timeline: 686 instead of 765 images/s under
 # CY_DDP_FORCE=1).  Eight queues keep them apart.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# dmabuf IPC is what RCCL needs on this driver; the HSA runtime reads it when it initialises (the first HIP call), so here, not later
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import torch
 import torch.distributed as dist
@@ -336,8 +344,8 @@ def self_launch(n, argv, script=None, need_gpus=True):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='train608', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the configuration\'s)')
     ap.add_argument('--size', type=int, default=None)
