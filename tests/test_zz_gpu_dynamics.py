@@ -83,15 +83,20 @@ def _agreement(a, b):
 
 
 # What the 16-bit modes hold against the fp32 parity mode on the conditioned net, ONE step on a batch of the conditioning run.
-# VERDICT r3 next #1a asked cosine >= 0.99 (f16) / 0.97 (bf16), loss 2e-3, probabilities 2e-2 and "if even a conditioned net does
-# not agree, that is a finding".  It is: measured on the MI355X over four sessions f16 0.958-0.965 / 0.960-0.973 (50 / 100 steps), bf16
-# 0.71-0.76 / 0.75-0.79, loss rel 1e-4...9e-4 (f16) and 3e-4...1.3e-2 (bf16), probabilities max 3.0e-2 (f16).  What it is a finding ABOUT is settled by two controls in the same test: (1) the fp32
-# default mode (atomics) against the fp32 deterministic mode gives 0.99993 -- the snapshot is well conditioned for float32;
-# (2) the REFERENCE'S OWN float32 arithmetic with ideal 16-bit storage of the tensors a half-precision implementation keeps in
-# memory (oracle storage_round: conv inputs, weights copies, pre-BN outputs and their gradients rounded, everything else
-# float32) deviates from float32 by the same angle -- see test_16bit_step_matches_ideal_16bit_storage.  The bounds below are
-# the measured values with margin.
-COND = {'f16': dict(cos=0.93, loss=2e-3, prob=5e-2), 'bf16': dict(cos=0.55, loss=3e-2, prob=0.35)}
+# VERDICT r3 next #1a asked cosine >= 0.99 (f16) / 0.97 (bf16) and "if even a conditioned net does not agree, that is a finding".
+# It is a finding about the FORMAT, settled by controls (each bound below is stated ONCE as control x margin and is not re-sized
+# after a failure -- VERDICT r4 next #2c):
+#   * f16: the control is the mode's own run-to-run agreement, measured in the same test -- a REPEAT of the f16 step against the
+#     first (atomics' order moves one f16 rounding somewhere and the net amplifies it): 0.972-0.983 over five sessions, while f16 vs
+#     f32 was 0.958-0.973.  Asserted: cos(f16, f32) >= cos(f16 repeat, f16) - 0.04, i.e. twice the largest gap seen (0.021).
+#   * bf16: its control needs the CPU oracle and lives in test_16bit_step_matches_ideal_16bit_storage (device cosine >= the
+#     reference's own arithmetic with ideal bf16 storage - 0.15); here only a floor far below every observation (0.71-0.80).
+#   * loss / probabilities: the largest values of five sessions x 2 (f16: loss rel 9e-4, probabilities 3.9e-2; bf16: 1.4e-2, 0.24),
+#     rounded up.
+#   * the fp32 default mode (atomics) against the fp32 deterministic mode gives 0.99993-0.99998: the snapshot is well conditioned
+#     for float32, so the angles above are the 16-bit formats', not the test's.
+COND = {'f16': dict(cos=0.90, loss=2e-3, prob=8e-2), 'bf16': dict(cos=0.55, loss=3e-2, prob=0.5)}
+F16_VS_REPEAT_MARGIN = 0.04
 
 
 def test_conditioned_net_16bit_step_agrees_with_fp32(f32_run):
@@ -127,6 +132,10 @@ def test_conditioned_net_16bit_step_agrees_with_fp32(f32_run):
         assert cos >= b['cos'], (dtype, cos)
         assert rel <= b['loss'], (dtype, rel)
         assert pmax <= b['prob'], (dtype, pmax)
+    for n in (SNAP_AT, N_STEPS):       # f16 against its own run-to-run agreement (the control), both snapshots
+        row = table[(n, 'seen')][1]
+        assert row['f16'][0] >= row['f16 repeat vs f16'][0] - F16_VS_REPEAT_MARGIN, (n, row['f16'][0], row['f16 repeat vs f16'][0])
+        assert row['f32 default'][0] >= 0.9999, row['f32 default']        # (the float32 control)
 
 
 @pytest.mark.parametrize('dtype,tdt', [('f16', torch.float16), ('bf16', torch.bfloat16)])
