@@ -694,7 +694,14 @@ def run_worker(argv, map_file, timeout=1500):
     import subprocess
     import threading
     cmd = [sys.executable, os.path.abspath(__file__), '--worker', '--map-file', map_file] + [x for x in argv if x != '--worker']
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    def die_with_parent():       # (a supervisor killed by its caller must not leave a worker holding the GPU)
+        try:
+            import ctypes
+            import signal
+            ctypes.CDLL(None).prctl(1, signal.SIGKILL)      # PR_SET_PDEATHSIG
+        except Exception:      # noqa: BLE001
+            pass
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, preexec_fn=die_with_parent)
     err = []
 
     def pump():
