@@ -338,7 +338,7 @@ int cy_yolo_loss_multi(int nheads, const cy_head_in* heads_host, int B, int A, i
  * cy_yolo_loss_multi_workspace(..., nT_cap)), *nT_dev (0 <= *nT_dev <= nT_cap) of them are live; rows beyond are never read.  All
  * arguments then repeat from step to step for every batch whose count falls into the same bucket, so ONE recorded launch list
  * (cy_run_plan) serves them -- the reference's dataloader yields a different number of boxes almost every step
- * (kitti_dataset.py:104-121, collate_fn :232-243).  Results are identical to cy_yolo_loss_multi(..., nT = *nT_dev, ...). */
+ * (kitti_dataset.py:110-114, collate_fn :216-223).  Results are identical to cy_yolo_loss_multi(..., nT = *nT_dev, ...). */
 int cy_yolo_loss_multi_n(int nheads, const cy_head_in* heads_host, int B, int A, int C, const float* targets, int nT_cap,
                          const int32_t* nT_dev, float img_size, float ignore_thresh, int use_giou, void* workspace, float* out,
                          int rows_total, cy_stream_t s);
