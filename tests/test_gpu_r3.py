@@ -390,3 +390,33 @@ def test_batched_heads_equal_per_head_calls(giou):
         assert torch.equal(met1[h], met2[h]), (h, met1[h], met2[h])
         assert torch.equal(dl1[h], dl2[h]), h
     assert float(met1[0][19]) == 1.0                            # the rejected row is counted, not assigned
+    # ... and with the row count ON THE DEVICE (cy_yolo_loss_multi_n, round 5): launches sized for a 64-row bucket, the buffer's
+    # rows beyond the batch's count hold GARBAGE (stale rows of an earlier batch, a NaN row, an out-of-range sample index) that
+    # must never be looked at: everything bit-identical again -- for this batch, for a shorter one and for an empty one
+    for cap, n_live in ((64, nT), (128, nT), (64, 5), (64, 0)):
+        buf = torch.full((cap + 8, 8), float('nan'), device=DEV)
+        buf[:nT] = tg
+        buf[nT:nT + 6] = tg[:6] * 0.5 + 0.1                      # plausible-looking stale rows
+        buf[nT + 6, 0] = 99.0
+        nt_dev = torch.tensor([n_live], dtype=torch.int32, device=DEV)
+        out3 = torch.zeros_like(out2)
+        met3 = [torch.zeros(20, device=DEV) for _ in Gs]
+        dl3 = [torch.empty_like(l) for l in logits]
+        table3 = ops.make_head_table([(logits[h], dl3[h], met3[h], anchors[h], Gs[h], offs[h]) for h in range(3)])
+        ws3 = torch.empty(ops.yolo_loss_multi_workspace(Gs, B, A, C, cap), dtype=torch.uint8, device=DEV)
+        ops.yolo_loss_multi(table3, 3, B, A, C, buf, S, 0.7, giou, ws3, out3, rows_total, cap=cap, nt_dev=nt_dev)
+        # the reference for a shorter batch: the exact-count entry point on the first n_live rows
+        out4 = torch.zeros_like(out2)
+        met4 = [torch.zeros(20, device=DEV) for _ in Gs]
+        dl4 = [torch.empty_like(l) for l in logits]
+        table4 = ops.make_head_table([(logits[h], dl4[h], met4[h], anchors[h], Gs[h], offs[h]) for h in range(3)])
+        ops.yolo_loss_multi(table4, 3, B, A, C, tg[:n_live].contiguous() if n_live else None, S, 0.7, giou, ws, out4, rows_total)
+        torch.cuda.synchronize()
+        same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0))      # noqa: E731
+        assert torch.equal(out3, out4), (cap, n_live)
+        for h in range(3):
+            # (an EMPTY batch has 0 / 0 means -- NaN metrics, as in the reference's empty-target step -- in both forms alike)
+            assert same(met3[h], met4[h]), (cap, n_live, h, met3[h], met4[h])
+            assert same(dl3[h], dl4[h]), (cap, n_live, h)
+            if n_live:
+                assert torch.isfinite(dl3[h]).all() and torch.isfinite(met3[h]).all()
