@@ -22,7 +22,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 # (No element-wise gradient bound HERE: at this random init the net amplifies a 1e-7 perturbation to 4e-2 -- the oracle's own
 # float32 and float64 runs differ by that, profiles/r04_oracle_f64_vs_f32.txt -- so 16-bit gradients are uncorrelated with the
 # reference's element by element; round 3 "bounded" them at 300 %, which bounded nothing.  The element-wise evidence for the
-# 16-bit modes is on a CONDITIONED net, with controls: tests/test_gpu_r4.py::test_conditioned_net_16bit_step_agrees_with_fp32 and
+# 16-bit modes is on a CONDITIONED net, with controls: tests/test_zz_gpu_dynamics.py::test_conditioned_net_16bit_step_agrees_with_fp32 and
 # ::test_16bit_step_matches_ideal_16bit_storage.)
 BANDS = {
     #        loss rel, prob median, prob max, grad-norm ratio median window
