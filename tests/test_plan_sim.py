@@ -223,3 +223,26 @@ def test_training_outputs_are_not_aliased_and_stale_backward_raises(monkeypatch)
     with pytest.raises(CyoloError):
         loss_a.backward()
     loss_b.backward()                                          # the latest forward is fine
+
+
+def test_arena_red_zones_name_the_overrun_buffer():
+    """models/engine.py::Arena (what tests/test_gpu_redzone.py allocates every engine buffer from): bands of 0xFF on both sides of each
+    buffer inside its own allocation; a write past either end is reported with the buffer's name, the side and the distance."""
+    import torch
+    from complex_yolov4_pytorch_amd.models.engine import Arena
+    plain = Arena('cpu', 0)
+    assert plain.new('x', (3, 4), torch.float32, zero=True).abs().sum() == 0 and plain.violations() == []
+    ar = Arena('cpu', 512)
+    a = ar.new('a', 100, torch.float16)
+    b = ar.new('b', (4, 25), torch.float32, zero=True)
+    assert a.shape == (100,) and b.shape == (4, 25) and float(b.abs().sum()) == 0.0
+    assert torch.isnan(a.float()).all()                     # un-zeroed buffers start as 0xFFFF = NaN: an uninitialised READ shows up too
+    assert ar.violations() == []
+    a.fill_(1.0); b.fill_(2.0)
+    assert ar.violations() == []                            # writing INSIDE is fine
+    raw_b = ar.blocks[1][1]
+    raw_b[512 + 400 + 3] = 0                                # 4 bytes past the end of b (400 bytes)
+    raw_a = ar.blocks[0][1]
+    raw_a[512 - 2] = 7                                      # 2 bytes before the start of a
+    bad = ar.violations()
+    assert ('b', 'above', 4) in bad and ('a', 'below', 2) in bad and len(bad) == 2, bad
