@@ -188,6 +188,63 @@ def replay_ddp(out):
         json.dump(res, f)
 
 
+def two_ranks_one_gpu(out, rank):
+    """Two data-parallel ranks with REAL kernels (both on cuda:0 -- the box has one GPU -- exchanging over gloo, which stages CUDA
+    tensors through the host): RcclDataParallel's hooks, bucketed all-reduce on its side stream, the 1/world factor folded into the
+    backward kernels and the recorded launch lists, under an actual second rank.  Leaves: the rank's LOCAL gradient of the first
+    batch (plain model), the data-parallel model's gradient after the exchange, parameter hashes after three Adam steps."""
+    rank = int(rank)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29541')
+    os.environ['RANK'], os.environ['WORLD_SIZE'] = str(rank), '2'
+    import torch
+    import torch.distributed as dist
+    import complex_yolov4_pytorch_amd.synthetic as syn
+    from complex_yolov4_pytorch_amd.optim import FusedAdam
+    from complex_yolov4_pytorch_amd.parallel import RcclDataParallel
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    B, S = 2, 416
+    batches = [(syn.bev_images(B, S, seed=60 + 10 * i + rank).to(dev), syn.targets(B, 5 + rank, S, seed=60 + 10 * i + rank).to(dev)) for i in range(3)]
+    plain = _model('f16', deterministic=True)
+    loss, _ = plain(*batches[0])
+    loss.backward()
+    g_local = plain.flat_grad.detach().clone().cpu()
+    plain.release_engines()
+    del plain
+    try:
+        dist.init_process_group('gloo', rank=rank, world_size=2)
+        probe = torch.ones(4, device=dev)
+        dist.all_reduce(probe)
+        assert float(probe[0]) == 2.0
+    except Exception as e:      # noqa: BLE001 -- a gloo build without CUDA-tensor support: nothing to test here
+        with open(out, 'w') as f:
+            json.dump(dict(skip=repr(e)), f)
+        return
+    model = _model('f16', deterministic=True)
+    net = RcclDataParallel(model, bucket_bytes=32 << 20)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    losses, g_ddp = [], None
+    for i in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = net(*batches[i])
+        loss.backward()
+        if i == 0:
+            torch.cuda.synchronize()
+            g_ddp = model.flat_grad.detach().clone().cpu()
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    eng = next(iter(model._engines.values()))
+    torch.save(dict(g_local=g_local, g_ddp=g_ddp), out + '.pt')
+    res = dict(losses=losses, params=_sha(torch.cat([p.detach().reshape(-1) for p in model.parameters()])),
+               replayed=int(eng.replayed), passes=int(eng.passes))
+    dist.barrier()
+    dist.destroy_process_group()
+    with open(out, 'w') as f:
+        json.dump(res, f)
+
+
 if __name__ == '__main__':
     job, args = sys.argv[1], sys.argv[2:]
-    {'det_hash': det_hash, 'rccl': rccl, 'wgrad_case': wgrad_case, 'replay_ddp': replay_ddp}[job](*args)
+    {'det_hash': det_hash, 'rccl': rccl, 'wgrad_case': wgrad_case, 'replay_ddp': replay_ddp, 'two_ranks_one_gpu': two_ranks_one_gpu}[job](*args)

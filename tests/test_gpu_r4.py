@@ -506,6 +506,37 @@ def test_replay_under_the_data_parallel_wrapper(tmp_path):
     assert a['per_step'] == b['per_step'] and all(len(c) >= 2 for c in a['per_step'])      # bucketed all-reduces every step
 
 
+def test_two_data_parallel_ranks_with_real_kernels(tmp_path):
+    """No 8-GPU node was ever available to the builder, and the nccl test above has ONE rank.  This one has TWO: both on this box's
+    single GPU, exchanging over gloo (CUDA tensors staged through the host) -- real kernels, real hooks, a real second rank.
+    After the first backward each rank's gradient must be the mean of the two ranks' LOCAL gradients (computed by plain models
+    before the process group exists): the backward kernels emit gradient / 2, the SUM all-reduce adds them -- exact halvings and
+    one rounding per element either way, so the comparison is bit for bit.  After three Adam steps both ranks hold identical
+    parameters, and the later steps replayed their recorded launch lists around the all-reduce hooks."""
+    import socket
+    s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'CY_TUNE_RECORD', 'CY_DDP_FORCE')}
+    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    outs = [os.path.join(str(tmp_path), 'rank%d.json' % r) for r in (0, 1)]
+    procs = [subprocess.Popen([sys.executable, '-m', 'tests.gpu_workers', 'two_ranks_one_gpu', outs[r], str(r)], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs[0][-3000:] + logs[1][-3000:]
+    res = [json.load(open(o)) for o in outs]
+    if any('skip' in r for r in res):
+        pytest.skip('gloo without CUDA-tensor support here: %s' % [r.get('skip') for r in res])
+    t = [torch.load(o + '.pt') for o in outs]
+    want = (t[0]['g_local'] + t[1]['g_local']) / 2
+    for r in (0, 1):
+        assert torch.equal(t[r]['g_ddp'], want), (r, float((t[r]['g_ddp'] - want).abs().max()), float(want.abs().max()))
+    assert not torch.equal(t[0]['g_local'], t[1]['g_local'])          # (the ranks really had different batches)
+    assert res[0]['params'] == res[1]['params']
+    assert all(np.isfinite(res[0]['losses'])) and res[0]['losses'] != res[1]['losses']
+    assert res[0]['replayed'] >= 2, res[0]
+    print('two ranks on one GPU over gloo: gradient = mean of the local gradients bit for bit (max |g| %.3e), parameters equal after 3 steps, '
+          '%d of %d passes replayed' % (float(want.abs().max()), res[0]['replayed'], res[0]['passes']))
+
+
 # ---- bench.py --gpus N ---------------------------------------------------------------------------------------------------------
 def _bench(extra_env, *args):
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'CY_TUNE_RECORD')}
