@@ -743,6 +743,19 @@ def supervise(a, argv):
     map_file = os.path.join(tempfile.gettempdir(), 'cy_bench_map_%d.json' % os.getpid())
     faults, full, part, tries = [], None, None, 0
     attempts = 2 if world == 1 else 1       # (a retry under a launcher would need every rank to agree on it)
+    if rank == 0 and world > 1:
+        # under a launcher a rank that dies makes the launcher terminate the others -- rank 0's supervisor included; it must
+        # still leave ONE line saying so (a dead rank used to mean no line at all)
+        import signal
+
+        def terminated(signum, frame):
+            emit({'metric': 'BEV images/s (%dx%d) train step' % (a.size, a.size), 'value': None, 'unit': 'images/s', 'n_gpus': world,
+                  'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                  'dtype': a.dtype, 'data': 'synthetic', 'config': {'workload': a.config, 'global_batch': world * a.batch},
+                  'roofline': None, 'cpu_baseline': None,
+                  'error': 'rank 0 was terminated by the launcher (signal %d) before its worker finished: another rank died' % signum})
+            os._exit(1)
+        signal.signal(signal.SIGTERM, terminated)
     for attempt in range(attempts):
         tries += 1
         rc, f2, p2, err = run_worker(argv, map_file)
