@@ -117,14 +117,13 @@ def test_rank0_supervisor_leaves_a_line_when_the_launcher_terminates_it(tmp_path
     """Under a launcher a dying rank makes the launcher SIGTERM the others; rank 0's supervisor must still print ONE line with `error`
     ("under self_launch a dead rank must still produce a line")."""
     import signal
-    import time
     code = ('import sys, time; sys.path.insert(0, %r); import bench\n'
-            'bench.run_worker = lambda argv, map_file, timeout=0: (time.sleep(60), (0, None, None, ""))[1]\n'
+            'bench.run_worker = lambda argv, map_file, timeout=0: (sys.stderr.write("READY\\n"), sys.stderr.flush(), time.sleep(60), (0, None, None, ""))[3]\n'
             'argv = ["--gpus", "2", "--steps", "2", "--warmup", "1"]\n'
             'sys.exit(bench.supervise(bench.parse_args(argv), argv))\n' % ROOT)
     env = dict(os.environ, RANK='0', WORLD_SIZE='2', LOCAL_RANK='0', OMP_NUM_THREADS='1')
     p = subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
-    time.sleep(6)                                   # (import torch + the supervisor reaching its worker)
+    assert 'READY' in p.stderr.readline()           # (the supervisor has installed its handler and is waiting for its worker)
     p.send_signal(signal.SIGTERM)
     out, err = p.communicate(timeout=60)
     lines = [ln for ln in out.splitlines() if ln.startswith('{')]
