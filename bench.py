@@ -688,12 +688,12 @@ def diagnose_fault(stderr_text, map_file):
     return d
 
 
-def run_worker(argv, map_file, timeout=1500):
+def run_worker(argv, map_file, timeout=1500, script=None):
     """One worker process of this script -> (exit status, last complete JSON line or None, last partial line or None, stderr).
     stderr is forwarded line by line (stage markers stay visible while the run is alive) and kept for the diagnosis."""
     import subprocess
     import threading
-    cmd = [sys.executable, os.path.abspath(__file__), '--worker', '--map-file', map_file] + [x for x in argv if x != '--worker']
+    cmd = [sys.executable, os.path.abspath(script or __file__), '--worker', '--map-file', map_file] + [x for x in argv if x != '--worker']      # (script: tests)
     def die_with_parent():       # (a supervisor killed by its caller must not leave a worker holding the GPU)
         try:
             import ctypes
@@ -711,13 +711,16 @@ def run_worker(argv, map_file, timeout=1500):
             sys.stderr.flush()
     t = threading.Thread(target=pump, daemon=True)
     t.start()
-    try:
-        out, _ = p.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        p.kill()
-        out, _ = p.communicate()
-        err.append('bench.py supervisor: worker killed after %d s\n' % timeout)
+    # (one reader per pipe: the thread owns stderr, this thread stdout -- communicate() would read stderr too and swallow lines)
+    killed = []
+    timer = threading.Timer(timeout, lambda: (killed.append(1), p.kill()))
+    timer.start()
+    out = p.stdout.read()
+    p.wait()
+    timer.cancel()
     t.join(timeout=5)
+    if killed:
+        err.append('bench.py supervisor: worker killed after %d s\n' % timeout)
     full = part = None
     for ln in (out or '').splitlines():
         if ln.startswith('{'):

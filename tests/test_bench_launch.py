@@ -130,3 +130,33 @@ def test_rank0_supervisor_leaves_a_line_when_the_launcher_terminates_it(tmp_path
     assert p.returncode == 1 and len(lines) == 1, (p.returncode, out, err[-500:])
     d = json.loads(lines[0])
     assert d['value'] is None and d['n_gpus'] == 2 and 'terminated by the launcher' in d['error']
+
+
+FAKE_WORKER = """import json, os, sys, time
+mode = sys.argv[-1]
+for i in range(200):
+    sys.stderr.write("[bench %7.2fs] stage %d\\n" % (i, i))
+print(json.dumps({"partial": True, "value": 1.0}), flush=True)
+if mode == "hang":
+    time.sleep(60)
+if mode == "die":
+    sys.stderr.write("Memory access fault by GPU node-2 (Agent handle: 0x1) on address 0x1000. Reason: Unknown.\\n")
+    sys.stderr.flush()
+    os.abort()
+print(json.dumps({"value": 2.0}), flush=True)
+"""
+
+
+def test_run_worker_keeps_both_pipes_apart(tmp_path):
+    """bench.run_worker against a stand-in worker script: every stderr line is forwarded AND kept for the diagnosis, the partial and
+    the full line are told apart, a non-zero exit status comes back, a worker that hangs is killed at the timeout."""
+    bench = _bench_module()
+    fake = tmp_path / 'fake_bench.py'
+    fake.write_text(FAKE_WORKER)
+    rc, full, part, err = bench.run_worker(['ok'], str(tmp_path / 'map.json'), script=str(fake))
+    assert rc == 0 and full == {'value': 2.0} and part['value'] == 1.0 and err.count('stage') == 200
+    rc, full, part, err = bench.run_worker(['die'], str(tmp_path / 'map.json'), script=str(fake))
+    assert rc != 0 and full is None and part['value'] == 1.0 and 'Memory access fault' in err and err.count('stage') == 200
+    assert bench.diagnose_fault(err, str(tmp_path / 'nomap.json'))['address'] == '0x1000'
+    rc, full, part, err = bench.run_worker(['hang'], str(tmp_path / 'map.json'), timeout=3, script=str(fake))
+    assert rc != 0 and full is None and part is not None and 'killed after 3 s' in err
