@@ -805,6 +805,10 @@ def supervise(a, argv):
             line['other_configs'] = others
         if not a.no_cpu_baseline:
             stage('cpu_baseline (oracle on the host cores)')
+            # (torch's autograd engine asks the HIP runtime for its device count the first time backward() runs: hide the GPUs
+            # from THIS process -- every GPU process of the run has already been started -- so that the supervisor stays without
+            # any GPU state to the end)
+            os.environ['HIP_VISIBLE_DEVICES'] = os.environ['ROCR_VISIBLE_DEVICES'] = ''
             try:
                 line['cpu_baseline'] = cpu_baseline(2, a.size)
             except Exception as e:      # noqa: BLE001
