@@ -246,3 +246,10 @@ def test_arena_red_zones_name_the_overrun_buffer():
     raw_a[512 - 2] = 7                                      # 2 bytes before the start of a
     bad = ar.violations()
     assert ('b', 'above', 4) in bad and ('a', 'below', 2) in bad and len(bad) == 2, bad
+
+
+def test_target_row_buckets():
+    """The batched heads are sized for the 64-row bucket of the batch's target count (cy_yolo_loss_multi_n reads the live count on the
+    device): every count of a bucket shares one recorded launch list."""
+    from complex_yolov4_pytorch_amd.models.engine import Engine
+    assert [Engine._rows_bucket(n) for n in (0, 1, 63, 64, 65, 128, 129, 1000)] == [64, 64, 64, 64, 128, 128, 192, 1024]
