@@ -517,6 +517,7 @@ def test_two_data_parallel_ranks_with_real_kernels(tmp_path):
     s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'CY_TUNE_RECORD', 'CY_DDP_FORCE')}
     env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('GLOO_SOCKET_IFNAME', 'lo')          # (the box's hostname may not resolve: both ranks are local anyway)
     outs = [os.path.join(str(tmp_path), 'rank%d.json' % r) for r in (0, 1)]
     procs = [subprocess.Popen([sys.executable, '-m', 'tests.gpu_workers', 'two_ranks_one_gpu', outs[r], str(r)], cwd=ROOT, env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
