@@ -477,7 +477,7 @@ static int conv_igemm_impl(const void* g, int N, int GH, int GW, int GC, int ldg
     p.OH = OH; p.OW = OW; p.OC = OC; p.ldo = ldo;
     p.ks = ks; p.stride = stride; p.pad = pad; p.transposed = (flags & CY_CONV_TRANSPOSED) ? 1 : 0;
     p.K = ks * ks * GC; p.M = N * OH * OW; p.wrows = wrows; p.flags = flags;
-    p.mtiles = p.ntiles = 0; p.bm_eff = 0;
+    p.mtiles = p.ntiles = 0; p.bm_eff = 0; p.slab_rows = 0;
     p.stat_det = (flags & CY_CONV_STATS_DET) ? 1 : 0;
     if (p.M <= 0 || OC <= 0) return CY_ERR_ARG;
     if ((flags & CY_CONV_BNBWD_SUMS) && (!bn_mean || (flags & (CY_CONV_STATS | CY_CONV_AFFINE_ACT | CY_CONV_BIAS_F32OUT))))

@@ -58,6 +58,7 @@ struct IgemmParams {
     float* bn_zero;
     int bn_zero_n;
     int* ticket;
+    int slab_rows;                // conv3x3_slab_kernel (conv_pipe.hip): rows of one input slab (tile pixels + 2 GW + 2, a multiple of 8)
 };
 
 // What a block needs to know about ITS pixel lattice and taps: the launch's own (ordinary launches, one parity class per

@@ -28,6 +28,11 @@ def _wgrad_rows(rec):
 
 
 _PW_DIRECT = ((64, 64), (128, 64), (64, 128), (64, 32), (32, 64))    # (Cin, Cout) of the 1x1 streaming kernel (conv_direct.hip)
+def _slab_shape(rec):
+    """3x3 / stride 1 / pad 1: what the slab kernel of conv_pipe.hip takes (forward and dgrad alike)."""
+    return rec['ks'] == 3 and rec['stride'] == 1 and rec['pad'] == 1
+
+
 _CONV_TUNE_MEMO = {}      # (kind, shape key) -> best kernel / tile hint, shared by every engine of the process
 # tools/make_tune_cache.py only: lets the process that PRODUCES the persisted table time deterministic engines too (their
 # statistics-table layout differs, so they have keys of their own); everywhere else deterministic=True never times
@@ -812,13 +817,13 @@ class Engine:
         return (getattr(self.device, 'type', str(self.device)) == 'cuda' and self.dt != CY_F32 and hasattr(ops, 'CONV_TILE_HINTS')
                 and os.environ.get('CY_CONV_AUTOTUNE', '1') != '0')
 
-    def _time_hints(self, key, launch, cin, cout, ks=0):
+    def _time_hints(self, key, launch, cin, cout, ks=0, slab=False):
         """Best kernel / tile hint for one conv launch shape: looked up (tune.py) or timed (1 warm-up + CY_TUNE_REPS
         launches per candidate between HIP events, the fastest kept).  The 4-wave and the 8-wave kernels are within +-10 % of each other on v4's layers and
         the winner depends on how tiles quantise over the 256 CUs, so it is measured, once per shape and process."""
-        return self._time_hints_t(key, launch, cin, cout, ks=ks)[0]
+        return self._time_hints_t(key, launch, cin, cout, ks=ks, slab=slab)[0]
 
-    def _time_hints_t(self, key, launch, cin, cout, pipe_only=False, ks=0, hints=None, extra=()):
+    def _time_hints_t(self, key, launch, cin, cout, pipe_only=False, ks=0, hints=None, extra=(), slab=False):
         """-> (best hint, its time in ms per launch); pipe_only leaves the 4-wave kernels out and returns (None, None)
         when the pipelined kernel does not take the shape.  Order of authority: this process's memo, the persisted table
         (tune.py), then -- default mode only -- a timing run over the candidates (``hints`` overrides the candidate list).
@@ -842,6 +847,8 @@ class Engine:
                 hints.append(10)      # 1x1 streams: the direct kernel, also below the library's own size threshold
             if cin % 64 == 0 and cout % 8 == 0:
                 hints += [h for h in ops.CONV_TILE_HINTS if h != 1 and not (h in (3, 8) and cout <= 64)]
+                if slab and cout > 64:
+                    hints += list(ops.CONV_SLAB_HINTS)      # 3x3 / stride 1: the slab kernel (conv_pipe.hip)
         reps = int(os.environ.get('CY_TUNE_REPS', '3'))
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best, best_t = (None if pipe_only else 1), None
@@ -880,7 +887,7 @@ class Engine:
                 key = ('fwd', self.dt, self.det, xv.N, xv.H, xv.W, xv.C, xv.ld, raw.C, raw.ld, rec['ks'], rec['stride'])
                 self._fwd_tile[idx] = self._time_hints(key, lambda h: ops.conv_igemm(
                     xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=self._stat_flags, stats=self.stats,
-                    tile=h), xv.C, raw.C, ks=rec['ks'])
+                    tile=h), xv.C, raw.C, ks=rec['ks'], slab=_slab_shape(rec))
             else:
                 out = self.view(rec['out'])
                 res = self.view(rec['res']) if rec['res'] is not None else None
@@ -888,7 +895,7 @@ class Engine:
                 key = ('eval', self.dt, xv.N, xv.H, xv.W, xv.C, xv.ld, out.C, out.ld, rec['ks'], rec['stride'], res is not None)
                 self._fwd_tile[idx] = self._time_hints(key, lambda h: ops.conv_bn_act_eval(
                     xv, self.wf[idx], cop, out, rec['ks'], rec['stride'], rec['pad'], vec[2], vec[3], ops.ACT[rec['act']], res,
-                    tile=h), xv.C, out.C, ks=rec['ks'])
+                    tile=h), xv.C, out.C, ks=rec['ks'], slab=_slab_shape(rec))
         if self.training and self.fused_bn and self.conv_bn_fused and not self.det and hasattr(ops, 'conv_bn_act_train'):
             self._autotune_fwd_fused()      # (atomic statistics bins: never in the bit-reproducible mode)
         self.stats.zero_()        # the timed launches added into the statistics table
@@ -971,7 +978,7 @@ class Engine:
                 s2 = (10,) if (rec['ks'] == 3 and rec['stride'] == 2 and dy.C == 64 and ref.C == 32) else ()
                 hint, t_plain = self._time_hints_t(key, lambda h: ops.conv_igemm(
                     dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], flags=flags, tile=h), dy.C, ref.C,
-                    ks=(1 if rec['ks'] == 1 and rec['stride'] == 1 else 0), extra=s2)
+                    ks=(1 if rec['ks'] == 1 and rec['stride'] == 1 else 0), extra=s2, slab=_slab_shape(rec))
                 self._dgrad_tile[(rec['idx'], ref.c0)] = hint
                 L = b.get('dx_sums', {}).get(ri) if can_fuse else None
                 if L is None:
@@ -982,7 +989,8 @@ class Engine:
                 fhint, t_fused = self._time_hints_t(('dgrad+sums', act, raw.ld) + key[1:], lambda h: ops.conv_dgrad_bn_sums(
                     dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], raw, vec[0], vec[1], vec[2], vec[3],
                     act, tbl, flags=flags, tile=h), dy.C, ref.C, pipe_only=True,
-                    extra=s2 or ((10,) if (rec['ks'] == 1 and rec['stride'] == 1 and (dy.C, ref.C) in _PW_DIRECT) else ()))
+                    extra=s2 or ((10,) if (rec['ks'] == 1 and rec['stride'] == 1 and (dy.C, ref.C) in _PW_DIRECT) else ()),
+                    slab=_slab_shape(rec))
                 if fhint is None:
                     continue
                 rows = ops.bn_bwd_rows(raw.M, raw.C, self.dt, False)

@@ -382,6 +382,12 @@ def conv_pipe_config(mode=1, cap=0, bn=0, variant=0, bm_eff=0):
     lib().call('cy_conv_pipe_config', int(mode), int(cap), int(bn), int(variant), int(bm_eff))
 
 
+def conv_slab_config(mode=1, bm_eff=0):
+    """Test / tool switch of the slab kernels (cy_conv_slab_config): mode 0 off, 1 on hints 11-13, + 2 the loader / compute variant,
+    + 4 / + 8 the 3- / 4-stage weight ring of the K-split kernel; bm_eff forces the tile's used pixels."""
+    lib().call('cy_conv_slab_config', int(mode), int(bm_eff))
+
+
 def conv_stats_rows(M, OC, det=False):
     return lib().raw('cy_conv_stats_rows_det' if det else 'cy_conv_stats_rows')(M, OC)
 
@@ -392,7 +398,8 @@ def bn_scratch_rows():
 
 
 CONV_TILE_SHIFT = 8
-CONV_TILE_HINTS = (1, 2, 3, 4, 5, 6, 7, 8, 9)   # 1: 4-wave kernels; 2-5: pipelined kernel, 128/192/256/384-pixel tile; 6: its own
+CONV_TILE_HINTS = (1, 2, 3, 4, 5, 6, 7, 8, 9)
+CONV_SLAB_HINTS = (12, 13)     # the slab kernel (3x3 / stride 1 / pad 1, > 64 output channels): 192 / 256-pixel tile (11: its own policy)   # 1: 4-wave kernels; 2-5: pipelined kernel, 128/192/256/384-pixel tile; 6: its own
 #                                                policy; 7-9: its loader/compute split with a 128/192/256-pixel tile
 
 

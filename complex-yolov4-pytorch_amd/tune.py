@@ -28,7 +28,7 @@ CACHE_PATH = os.path.join(_HERE, 'tune_cache', 'gfx950.json')
 
 # bump when the MEANING of an entry changes without a kernel edit (engine.py's split caps, hint numbering, key layout):
 # folded into the hash the table is validated against, so an older table is ignored instead of misread
-TABLE_VERSION = 2
+TABLE_VERSION = 3
 
 _sha = None
 _table = None
@@ -44,6 +44,11 @@ def sources_sha():
         for f in sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.h*'))):
             with open(f, 'rb') as fh:
                 h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+        # the compiler flags are part of what was measured: build.py's per-file flags change the code of every kernel
+        # (CY_BUILD_NO_SLP=1), and a library loaded from elsewhere (CY_LIBPATH) is not the one the table was measured on at all
+        from . import build as _build
+        h.update(repr((_build.FLAGS[:4], sorted((k, tuple(v)) for k, v in _build.EXTRA_FLAGS.items()))).encode())
+        h.update(b'libpath ' + os.environ.get('CY_LIBPATH', '').encode())
         _sha = h.hexdigest()[:16]
     return _sha
 

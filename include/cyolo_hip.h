@@ -130,6 +130,9 @@ int cy_nchw_to_nhwc(const float* x, int N, int C, int H, int W, int CPad, int dt
  *                               7-9 its loader / compute split (4 + 8 waves) with a 128 / 192 / 256-pixel tile
  *                               10 the direct streaming kernels of conv_direct.hip also where the library default would not
  *                               pick them (1x1 launches of fewer than 256 k pixels)
+ *                               11-13 the slab kernel of conv_pipe.hip (3x3 / stride 1 / pad 1, forward and dgrad, more than 64
+ *                               output channels: one halo'd slab of input pixels per 64-channel chunk in LDS serves all nine
+ *                               taps, wave pairs split the K step): 11 its own tile policy, 12 / 13 a 192 / 256-pixel tile
  *                               (the hint is ignored where that kernel does not apply: f32, first layers, fp32 output)
  * Returns the number of stats rows written through *stats_rows when non-NULL. */
 int cy_conv_igemm(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out, int OH,
@@ -171,7 +174,7 @@ int cy_conv_bn_act_eval(const void* g, int N, int GH, int GW, int GC, int ldg, c
  * Reference: the autograd graph of Conv2d -> BatchNorm2d -> Mish, darknet2pytorch.py:247-278.
  * Runs on the 8-wave pipelined kernel only: 16-bit dtype, stride 1, GC % 64 == 0, OC % 8 == 0, ldo % 8 == 0,
  * ldraw % 8 == 0, 16-byte aligned raw; anything else returns CY_ERR_ARG (the caller keeps the separate reduce pass).
- * flags: CY_CONV_TRANSPOSED, CY_CONV_ACCUM, CY_CONV_STATS_DET (one table row per pixel tile), CY_CONV_TILE(2..9). */
+ * flags: CY_CONV_TRANSPOSED, CY_CONV_ACCUM, CY_CONV_STATS_DET (one table row per pixel tile), CY_CONV_TILE(2..9, 11..13). */
 int cy_conv_dgrad_bn_sums(const void* g, int N, int GH, int GW, int GC, int ldg, const void* w, int wrows, void* out,
                           int OH, int OW, int OC, int ldo, int ks, int stride, int pad, int dtype, int flags,
                           const void* raw, int ldraw, const float* mean, const float* invstd, const float* scale,
@@ -194,6 +197,11 @@ int64_t cy_direct_launches(void);
  * 3: four loader waves + eight compute waves.
  * CY_CONV_PIPE=0 in the environment = mode 0. */
 int cy_conv_pipe_config(int mode, int cap, int bn, int variant, int bm_eff);
+/* Test / tool switch of the slab kernels (CY_CONV_TILE(11..13)).  mode bit 0: the hints select them (0: hints 11-13 fall
+ * through to the library default); + 2: the loader / compute variant (4 + 8 waves) instead of the shipped K-split wave pairs;
+ * + 4 / + 8: force the 3- / 4-stage weight ring of the K-split kernel (default: 4 stages where the LDS allows).  bm_eff > 0
+ * forces the pixels used of the tile capacity (clamped to it).  CY_CONV_SLAB=0 in the environment = mode 0. */
+int cy_conv_slab_config(int mode, int bm_eff);
 
 /* Number of rows (bins) of the stats table cy_conv_igemm adds into (16). */
 int cy_conv_stats_rows(int M, int OC);
