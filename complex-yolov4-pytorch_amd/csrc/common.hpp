@@ -36,14 +36,16 @@ static inline hipStream_t cy_s(cy_stream_t s) { return (hipStream_t)s; }
 
 // One-time per-kernel set-up (hipFuncSetAttribute of the dynamic LDS size) is per DEVICE: a process that drives several GPUs
 // (not the one-process-per-GPU layout bench.py uses, but the C ABI does not forbid it) must repeat it on each.  `mask` is the
-// caller's function-static word, bit d = done on device d.
+// caller's function-static word, bit d = done on device d.  Several host threads may first-launch the same instantiation at
+// once (the recorder is thread-local so that a prefetch thread and an eval engine can call the library concurrently): the mask
+// is updated with an atomic fetch-or (two threads that both see the bit clear both set the attribute, which is
+// idempotent).  hipGetDevice is asked every time: a thread may have switched devices since its last launch.
 static inline bool cy_first_use_on_device(unsigned long long& mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return true;
     const unsigned long long bit = 1ull << (dev & 63);
-    if (mask & bit) return false;
-    mask |= bit;
-    return true;
+    if (__atomic_load_n(&mask, __ATOMIC_RELAXED) & bit) return false;
+    return (__atomic_fetch_or(&mask, bit, __ATOMIC_RELAXED) & bit) == 0;
 }
 
 // ---- element traits: 16-byte chunk = CH elements ------------------------------------------------

@@ -64,6 +64,9 @@ class GraphedTrainStep:
     def _capture(self, x, tg):
         ops.check_device_tensor(x, 'GraphedTrainStep')
         sx, st = x.clone(), tg.clone()
+        for e in self.model._engines.values():
+            e.pin_retired = True          # a captured graph has buffer addresses baked in: nothing an engine retires may be freed
+        self.model.engine_budget_bytes = None      # ... and no engine may be evicted under it
         torch.cuda.synchronize(x.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

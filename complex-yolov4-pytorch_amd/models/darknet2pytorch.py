@@ -104,7 +104,15 @@ class Darknet(nn.Module):
         self.header = torch.IntTensor([0, 0, 0, 0])
         self.seen = 0
         self.cpu_outputs = True          # targets=None returns a CPU tensor like the reference (:228)
-        self._plans, self._engines = {}, {}
+        import collections
+        self._plans, self._engines = {}, collections.OrderedDict()      # engines in least-recently-used order (see _engine_for)
+        # Byte budget of the engine cache.  The reference changes img_size by +-96 every 10 batches and doubles it under mosaic
+        # (kitti_dataset.py:42-43,144,225-230): at batch 16 the seven mosaic geometries are ~7 x 54 GB of engines -- more than
+        # the GPU has.  Engines beyond the budget are evicted least-recently-used first, recorded launch lists and tuned
+        # choices (process-wide memo, persisted table) surviving in tune.py.  None: 60 % of the device's memory at first use;
+        # CY_ENGINE_BUDGET_GB overrides.
+        self.engine_budget_bytes = None
+        self.engine_evictions = 0
         self._plist = None
         self._grad_flat = None
         self._post_backward_hooks = []
@@ -219,10 +227,51 @@ class Darknet(nn.Module):
         if pk not in self._plans:
             self._plans[pk] = Plan(self.blocks, H, W, ops.chunk(self.dtype_code))
         ek = (N, H, W, self.training, str(x.device), self.deterministic)
-        if ek not in self._engines:
-            self._engines[ek] = Engine(self._plans[pk], N, self.dtype_code, x.device, self.training,
-                                       deterministic=self.deterministic)
-        return self._engines[ek]
+        eng = self._engines.get(ek)
+        if eng is not None:
+            self._engines.move_to_end(ek)
+            return eng
+        try:
+            eng = Engine(self._plans[pk], N, self.dtype_code, x.device, self.training, deterministic=self.deterministic)
+        except torch.OutOfMemoryError:
+            # the new geometry does not fit beside the cached ones: drop them all and try once more
+            self.engine_evictions += len(self._engines)
+            self.release_engines()
+            eng = Engine(self._plans[pk], N, self.dtype_code, x.device, self.training, deterministic=self.deterministic)
+        self._engines[ek] = eng
+        self._trim_engines(x.device)
+        return eng
+
+    def _engine_budget(self, device):
+        if self.engine_budget_bytes is None and getattr(device, 'type', str(device)) == 'cuda':
+            import os
+            gb = os.environ.get('CY_ENGINE_BUDGET_GB')
+            self.engine_budget_bytes = int(float(gb) * (1 << 30)) if gb else int(0.6 * torch.cuda.get_device_properties(device).total_memory)
+        return self.engine_budget_bytes
+
+    def engine_bytes(self):
+        """Device bytes held by the cached engines."""
+        return sum(e.nbytes() for e in self._engines.values())
+
+    def _trim_engines(self, device):
+        """Evict least-recently-used engines (never the newest) until the cache fits its byte budget; an engine a captured
+        hipGraph points into (graphed.GraphedTrainStep sets pin_retired) is never evicted."""
+        budget = self._engine_budget(device)
+        if not budget or len(self._engines) < 2:
+            return
+        sizes = {k: e.nbytes() for k, e in self._engines.items()}
+        total, newest, dropped = sum(sizes.values()), next(reversed(self._engines)), False
+        for k in list(self._engines):
+            if total <= budget:
+                break
+            if k == newest or self._engines[k].pin_retired:
+                continue
+            total -= sizes[k]
+            del self._engines[k]
+            self.engine_evictions += 1
+            dropped = True
+        if dropped and getattr(device, 'type', str(device)) == 'cuda':
+            torch.cuda.empty_cache()      # hand the evicted engines' blocks back: the next geometry's buffers have other sizes
 
     def release_engines(self):
         """Drop cached device storages (e.g. after multiscale training changed resolution)."""

@@ -183,6 +183,12 @@ class Engine:
         # superseded head workspaces are kept for the engine's lifetime: a hipGraph captured while one of them was current
         # (graphed.GraphedTrainStep) has its pointer baked into its kernel arguments and keeps writing there on every replay
         self._retired_ws = []
+        # ... unless nothing was ever captured: then only the recorded launch lists can still point at a superseded table, and
+        # those are dropped together with the key they were recorded under -- the list is bounded to the last MAX_RETIRED
+        # objects (work already queued on the two streams may still read the most recent ones).  graphed.GraphedTrainStep sets
+        # pin_retired before its first capture.  (a caller whose parameter / gradient tensors move every epoch --
+        # EMA swaps, load_state_dict(assign=True) -- used to leak a table per move for the engine's lifetime.)
+        self.pin_retired = False
         self._wgrad_ev, self._main_stream, self._side_scope = {}, None, None
         self._main_h = self._side_h = None      # raw stream handles of the pass under way (ops.stream_handle)
         self._fork_ev = self._join_ev = None    # ops.Event: main -> side before a fold, side -> main at the end of backward
@@ -330,6 +336,18 @@ class Engine:
             self._heads_on_side = False
         return self.outputs
 
+    MAX_RETIRED = 8          # superseded tables / workspaces kept alive behind the current ones (see pin_retired)
+
+    def _retire(self, obj):
+        self._retired_ws.append(obj)
+        if not self.pin_retired and len(self._retired_ws) > self.MAX_RETIRED:
+            del self._retired_ws[:len(self._retired_ws) - self.MAX_RETIRED]
+
+    def nbytes(self):
+        """Device bytes this engine holds (activations, gradients, packed weights, slabs, tables): what Darknet's engine cache
+        budgets (models/darknet2pytorch.py)."""
+        return sum(b for _, _, b in self.buffer_map())
+
     MAX_PROGRAMS = 64        # recorded launch lists kept per direction (one per 64-row bucket of the target count, loss scale, ...: ~150 KB each)
 
     def _remember(self, table, key, prog):
@@ -354,7 +372,7 @@ class Engine:
         cap = self._rows_bucket(nT)
         if self._tg_buf is None or self._tg_buf.shape[0] < cap or self._tg_buf.shape[1] != targets.shape[1]:
             if self._tg_buf is not None:
-                self._retired_ws.append(self._tg_buf)
+                self._retire(self._tg_buf)
             self._tg_buf = self.arena.new('targets', (2 * cap, targets.shape[1]), torch.float32, zero=True)
         if self._nt_dev is None:
             self._nt_dev = self.arena.new('live target rows', 1, torch.int32, zero=True)
@@ -387,7 +405,10 @@ class Engine:
             if self._pack_table is not None:
                 # programs recorded against the old table can no longer be looked up (their key holds the old addresses) but
                 # stay in the FIFO for a while: the table they point to must outlive them
-                self._retired_ws.append(self._pack_table)
+                self._retire(self._pack_table)
+                # every recorded pass is keyed by the parameter addresses: none of them can be looked up again
+                self._fwd_progs.clear()
+                self._bwd_progs.clear()
             items = [(w, self.wf[r['idx']], self.wd[r['idx']], _pad32(r['cout']), r['cin_pad']) for w, r in zip(ws, self.plan.convs)]
             self._pack_table = ops.make_pack_table(items, self.device)
             self._pack_key = key
@@ -434,7 +455,8 @@ class Engine:
         if recs[tail:]:
             groups.append(recs[tail:])
         if self._reduce_groups:
-            self._retired_ws.append(self._reduce_groups)      # (recorded backward passes hold the old tables' addresses)
+            self._retire(self._reduce_groups)      # (recorded backward passes hold the old tables' addresses ...)
+            self._bwd_progs.clear()                # (... and are keyed by the gradient addresses that just changed)
         self._reduce_groups = []
         for g in groups:
             items = []
@@ -589,7 +611,7 @@ class Engine:
         need = ops.yolo_loss_workspace(self.N, rec['G'], rec['A'], rec['C'], nT)
         if self.loss_ws[h] is None or self.loss_ws[h].numel() < need:
             if self.loss_ws[h] is not None:
-                self._retired_ws.append(self.loss_ws[h])
+                self._retire(self.loss_ws[h])
             self.loss_ws[h] = self.arena.new('loss_ws[%d]' % h, need, torch.uint8)
         dl = self.dlogits[h]
         if dl is None:
@@ -605,7 +627,7 @@ class Engine:
             wcap = cap if self._head_table is None else max(cap, 2 * self._head_table[2])     # room to grow: KITTI batches vary
             need = ops.yolo_loss_multi_workspace([r['G'] for r in recs], self.N, r0['A'], r0['C'], wcap)
             if self._head_table is not None:
-                self._retired_ws.append(self._head_table)      # (table and workspace: see __init__)
+                self._retire(self._head_table)      # (table and workspace: see __init__)
             ws = self.arena.new('heads workspace', need, torch.uint8)
             heads = []
             for r in recs:

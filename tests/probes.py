@@ -18,7 +18,38 @@ def build(force=False):
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
                                '-shared', '-o', LIB, SRC])
+    build_head_slp(force)
     return LIB
+
+
+# The reproducer of "packed f32 beside MFMA loses a result" (profiles/r05_head_race.txt): the product's yolo_head.hip compiled
+# WITH hipcc's SLP vectoriser -- the default -O3 flags, i.e. what the library shipped until round 5 -- into a library of its own.
+# Its cy_yolo_loss beside an MFMA-issuing conv kernel on another stream is the victim of tests/test_gpu_r6.py; the shipped build
+# (-fno-slp-vectorize for this file, build.py) is the control.
+PKG_CSRC = os.path.join(HERE, '..', 'complex-yolov4-pytorch_amd', 'csrc')
+HEAD_SLP_LIB = os.path.join(HERE, '_build', 'libcyolo_head_slp.so')
+
+
+def build_head_slp(force=False):
+    src = os.path.join(PKG_CSRC, 'yolo_head.hip')
+    deps = [src, os.path.join(PKG_CSRC, 'geometry.hpp'), os.path.join(PKG_CSRC, 'common.hpp')]
+    if force or not os.path.exists(HEAD_SLP_LIB) or os.path.getmtime(HEAD_SLP_LIB) < max(os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(HEAD_SLP_LIB), exist_ok=True)
+        subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+                               '-I' + os.path.join(HERE, '..', 'include'), '-I' + PKG_CSRC, '-Wno-unused-value',
+                               '-mllvm', '-amdgpu-promote-alloca-to-vector-limit=1024', '-shared', '-o', HEAD_SLP_LIB, src])
+    return HEAD_SLP_LIB
+
+
+def head_slp_lib():
+    """ctypes handle of the SLP build of the head kernels (cy_yolo_loss with the product's signature)."""
+    import complex_yolov4_pytorch_amd._lib  # noqa: F401  (torch's HIP runtime first)
+    dll = ctypes.CDLL(build_head_slp())
+    dll.cy_yolo_loss.restype = ctypes.c_int
+    dll.cy_yolo_loss.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                 ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_void_p, ctypes.c_void_p]
+    return dll
 
 
 def _lib():

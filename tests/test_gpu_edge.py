@@ -120,20 +120,28 @@ def _perm_step(cfg, dtype, B, S):
     loss2.backward()
     assert torch.isfinite(loss).all() and torch.isfinite(g0).all() and torch.isfinite(model.flat_grad).all()
     rel = float((model.flat_grad - g0).norm() / g0.norm())
-    print('%s %s permutation: loss %.4f vs %.4f, grad rel diff %.2e' % (cfg, dtype, float(loss.detach()), float(loss2.detach()), rel))
-    return float(loss.detach()), float(loss2.detach()), rel
+    # kink-free statistics of the same two gradients: the ratio of their norms, and the element-wise relative
+    # difference at the MEDIAN element -- a pre-activation that changes side of the leaky-ReLU kink moves the gradient along
+    # ONE path (a few elements by a lot: the norm of the difference), not the typical element
+    ratio = float(model.flat_grad.norm() / g0.norm())
+    d = (model.flat_grad - g0).abs() / (g0.abs() + 1e-3 * float(g0.abs().mean()))
+    med = float(d.median())
+    print('%s %s permutation: loss %.4f vs %.4f, grad rel diff %.2e, norm ratio %.6f, median element-wise rel diff %.2e'
+          % (cfg, dtype, float(loss.detach()), float(loss2.detach()), rel, ratio, med))
+    return float(loss.detach()), float(loss2.detach()), rel, ratio, med
 
 
 def test_train_step_is_batch_permutation_invariant_fp32():
     """Permuting the images (and the sample index of the targets) leaves loss and gradients unchanged: BN statistics,
     target assignment and the reductions do not depend on sample order (tiny cfg, fp32: tight)."""
-    l1, l2, rel = _perm_step('complex_yolov4_tiny.cfg', 'f32', 4, 608)
-    # The loss is tight.  The gradient bound is NOT a kernel tolerance: a permutation changes the summation order of the BatchNorm
-    # statistics, a pre-activation next to the leaky-ReLU kink may change side, and the gradient then moves discontinuously along
-    # that path -- measured over ten runs on the MI355X (round 5): 1.1e-3 ... 2.1e-3 nine times, 8.2e-3 once (which failed the
-    # former 5e-3 bound as the 6th test of a `pytest -x` run).  A sample-order dependence of the statistics, the target
-    # assignment or a reduction would show up at O(1).
+    l1, l2, rel, ratio, med = _perm_step('complex_yolov4_tiny.cfg', 'f32', 4, 608)
+    # The loss is tight.  The bound on the NORM OF THE DIFFERENCE is not a kernel tolerance: a permutation changes the summation
+    # order of the BatchNorm statistics, a pre-activation next to the leaky-ReLU kink may change side, and the gradient then moves
+    # discontinuously along that path -- measured over ten runs on the MI355X (round 5): 1.1e-3 ... 2.1e-3 nine times, 8.2e-3 once.
+    # What a sample-order dependence of the statistics, the target assignment or a reduction WOULD move -- also at the 1e-2 level,
+    # which that bound alone would let pass (ADVICE r5) -- are the kink-free statistics: the gradient's norm and its typical element.
     assert abs(l1 - l2) / l1 < 1e-5 and rel < 3e-2
+    assert abs(ratio - 1.0) < 2e-3 and med < 1e-3, (ratio, med)
 
 
 def test_full_size_train_step_permutation_invariant_loss():
@@ -142,7 +150,7 @@ def test_full_size_train_step_permutation_invariant_loss():
     identical step already differ by O(1) in direction (tools/perm_probe.py: fp32 4e-2, fp16 0.9; the fp32 atomics of
     the BN statistic bins reorder a 1e-7 perturbation that the net amplifies; the reference shows the same
     sensitivity, tests/test_plan_sim.py), so only finiteness is asserted for it here."""
-    l1, l2, rel = _perm_step('complex_yolov4.cfg', 'f16', 16, 608)
+    l1, l2, rel, _, _ = _perm_step('complex_yolov4.cfg', 'f16', 16, 608)
     assert abs(l1 - l2) / l1 < 1e-2
 
 

@@ -24,7 +24,7 @@ import collections, csv, glob, json, os, sys
 root, repo, tag = sys.argv[1:4]
 sys.path.insert(0, repo)
 import bench
-FAM = [('conv fwd/dgrad', ('igemm_fast_kernel', 'igemm_kernel', 'igemm_pipe_kernel', 'direct3x3_kernel', 'direct1x1_kernel', 'direct_s2dgrad_kernel')),
+FAM = [('conv fwd/dgrad', ('igemm_fast_kernel', 'igemm_kernel', 'igemm_pipe_kernel', 'direct3x3_kernel', 'direct1x1_kernel', 'direct_s2dgrad_kernel', 'conv3x3_slab')),
        ('wgrad', ('wgrad_dma_kernel', 'wgrad_kernel')), ('wgrad fold', ('wgrad_reduce',)), ('bn_act_fwd', ('bn_act_fwd',)),
        ('bn_bwd_reduce', ('bn_bwd_reduce',)), ('bn_bwd_apply', ('bn_bwd_apply',)), ('pack', ('pack_weights',)), ('adam', ('adam_multi',))]
 def fam(name):

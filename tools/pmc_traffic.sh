@@ -15,7 +15,7 @@ import csv, glob, json, os, sys, collections
 root = sys.argv[1]
 sys.path.insert(0, sys.argv[2])
 import bench
-FAM = [('igemm', ('igemm_fast_kernel', 'igemm_kernel', 'igemm_pipe_kernel', 'direct3x3_kernel', 'direct1x1_kernel', 'direct_s2dgrad_kernel')), ('wgrad', ('wgrad_dma_kernel', 'wgrad_kernel')),
+FAM = [('igemm', ('igemm_fast_kernel', 'igemm_kernel', 'igemm_pipe_kernel', 'direct3x3_kernel', 'direct1x1_kernel', 'direct_s2dgrad_kernel', 'conv3x3_slab')), ('wgrad', ('wgrad_dma_kernel', 'wgrad_kernel')),
        ('wgrad_reduce', ('wgrad_reduce',)), ('bn_act_fwd', ('bn_act_fwd',)), ('bn_bwd_reduce', ('bn_bwd_reduce',)),
        ('bn_bwd_apply', ('bn_bwd_apply',)), ('bn_bwd_finalize', ('bn_bwd_finalize',)), ('bn_finalize', ('bn_finalize',)),
        ('pack_weights', ('pack_weights',)), ('adam', ('adam_multi',))]

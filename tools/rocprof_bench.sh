@@ -35,7 +35,7 @@ tot = sum(r[0] for r in rows)
 print('per-step kernel time (difference of a %s-step and a %s-step run, one-time tuning launches cancel): %.3f ms' % ('4', '24', tot))
 fam = collections.OrderedDict()
 def family(k):
-    for f, pat in (('conv fwd/dgrad (igemm_*, direct*)', 'igemm|direct3x3|direct1x1'), ('wgrad', 'wgrad_dma|wgrad_kernel'), ('wgrad fold', 'wgrad_reduce'),
+    for f, pat in (('conv fwd/dgrad (igemm_*, conv3x3_slab*, direct*)', 'igemm|conv3x3_slab|direct3x3|direct1x1|direct_s2dgrad'), ('wgrad', 'wgrad_dma|wgrad_kernel'), ('wgrad fold', 'wgrad_reduce'),
                    ('bn_act_fwd', 'bn_act_fwd'), ('bn_bwd_reduce', 'bn_bwd_reduce'), ('bn_bwd_apply', 'bn_bwd_apply'),
                    ('bn finalisers', 'bn_finalize|bn_bwd_finalize'), ('adam', 'adam_multi'), ('pack', 'pack_weights'),
                    ('pools/upsample/slices', 'maxpool|upsample|slice|f32_to_view|nchw'), ('head', 'decode|assign|pairs|dense|giou|finalize_kernel|bias_grad')):
