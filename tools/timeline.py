@@ -25,7 +25,7 @@ main_q = max(byq, key=lambda q: len(byq[q]))
 
 
 def fam(n):
-    for f, pat in (('conv fwd/dgrad', 'igemm'), ('conv fwd/dgrad', 'direct3x3'), ('conv fwd/dgrad', 'direct1x1'), ('wgrad', 'wgrad_dma'), ('wgrad fold', 'wgrad_reduce'), ('bn_act_fwd', 'bn_act_fwd'),
+    for f, pat in (('conv fwd/dgrad', 'igemm'), ('conv fwd/dgrad', 'conv3x3_slab'), ('conv fwd/dgrad', 'direct_s2dgrad'), ('conv fwd/dgrad', 'direct3x3'), ('conv fwd/dgrad', 'direct1x1'), ('wgrad', 'wgrad_dma'), ('wgrad fold', 'wgrad_reduce'), ('bn_act_fwd', 'bn_act_fwd'),
                    ('bn_bwd_reduce', 'bn_bwd_reduce'), ('bn_bwd_apply', 'bn_bwd_apply'), ('adam', 'adam_multi'), ('pack', 'pack_weights')):
         if pat in n:
             return f
