@@ -1222,20 +1222,18 @@ int slabk_launch(const IgemmParams& p0, hipStream_t s, int force_nst) {
         return (ring > REUSE ? ring : REUSE) + 1024 + BM * 8;
     };
     int nst = need(4) <= 160 * 1024 ? 4 : 3;
-    if (force_nst >= 3 && force_nst <= 6) nst = force_nst;
+    if (force_nst == 3 || force_nst == 4) nst = force_nst;      // (5 and 6 stages measured no better: profiles/r06_conv_ablation.txt)
     const int smem = need(nst);
     if (smem > 160 * 1024) return CY_ERR_UNSUPPORTED;
     static unsigned long long attr_done = 0;      // bit d: set for HIP device d
     if (cy_first_use_on_device(attr_done)) {
 #define CY_ATTR(N_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_slabk_kernel<T, BM, BN, WN, N_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        CY_ATTR(3) CY_ATTR(4) CY_ATTR(5) CY_ATTR(6)
+        CY_ATTR(3) CY_ATTR(4)
 #undef CY_ATTR
     }
     const dim3 grid(p.mtiles * p.ntiles);
     if (nst == 3) hipLaunchKernelGGL((conv3x3_slabk_kernel<T, BM, BN, WN, 3>), grid, dim3(512), smem, s, p);
-    else if (nst == 4) hipLaunchKernelGGL((conv3x3_slabk_kernel<T, BM, BN, WN, 4>), grid, dim3(512), smem, s, p);
-    else if (nst == 5) hipLaunchKernelGGL((conv3x3_slabk_kernel<T, BM, BN, WN, 5>), grid, dim3(512), smem, s, p);
-    else hipLaunchKernelGGL((conv3x3_slabk_kernel<T, BM, BN, WN, 6>), grid, dim3(512), smem, s, p);
+    else hipLaunchKernelGGL((conv3x3_slabk_kernel<T, BM, BN, WN, 4>), grid, dim3(512), smem, s, p);
     CY_LAUNCH_CHECK();
     return 0;
 }
@@ -1310,7 +1308,7 @@ extern "C" int cy_conv_pipe_config(int mode, int cap, int bn, int variant, int b
 extern "C" int cy_conv_slab_config(int mode, int bm_eff) {
     g_slab_mode = mode & 1; g_pipe_bm_eff_slab = bm_eff;
     g_slab_variant = (mode & 2) ? 0 : 1;          // + 2: the loader / compute variant instead of the K-split wave pairs
-    g_slab_nst = (mode & 4) ? 3 : ((mode & 8) ? 4 : ((mode & 16) ? 5 : ((mode & 32) ? 6 : 0)));      // + 4 / 8 / 16 / 32: force a 3- / 4- / 5- / 6-stage weight ring
+    g_slab_nst = (mode & 4) ? 3 : ((mode & 8) ? 4 : 0);      // + 4 / + 8: force the 3- / 4-stage weight ring
     return 0;
 }
 

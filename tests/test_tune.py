@@ -51,7 +51,7 @@ def test_shipped_table_matches_the_kernel_sources(monkeypatch):
         if key[0] == 'wgrad':               # split, + 1000 = 64 x 64 tiles, < 0 = atomic mode (never shipped)
             assert 1 <= v[0] % 1000 <= 2048 and v[0] > 0, (k, v)
         elif key[0] in ('fwd', 'dgrad', 'eval'):
-            assert 0 <= v[0] <= 10, (k, v)   # tile hints of include/cyolo_hip.h
+            assert 0 <= v[0] <= 13, (k, v)   # tile hints of include/cyolo_hip.h (11-13: the slab kernels)
     for kind, least in (('fwd', 100), ('dgrad', 100), ('wgrad', 100), ('eval', 30), ('dgrad+sums', 50)):
         assert kinds.get(kind, 0) >= least, kinds
     assert tune.get(eval(next(iter(doc['entries'])))) is not None
@@ -127,10 +127,13 @@ def test_save_merges_into_a_table_of_the_same_sources_only(monkeypatch, tmp_path
 
 
 def test_sources_sha_covers_every_kernel_source(monkeypatch, tmp_path):
-    """The stamp changes with any byte of csrc/*.hip, *.hpp (that is what invalidates a table after a kernel edit)."""
+    """The stamp changes with any byte of csrc/*.hip, *.hpp (that is what invalidates a table after a kernel edit), with the
+    compiler flags the kernels are built with (build.py: CY_BUILD_NO_SLP=1 changes every kernel's code) and with CY_LIBPATH (a
+    library loaded from elsewhere is not the one the table was measured on) -- ADVICE r5."""
     import glob
     import hashlib
     tune = _fresh_tune(monkeypatch)
+    from complex_yolov4_pytorch_amd import build
     here = os.path.dirname(tune.__file__)
     files = sorted(glob.glob(os.path.join(here, 'csrc', '*.h*')))
     names = {os.path.basename(f) for f in files}
@@ -141,4 +144,12 @@ def test_sources_sha_covers_every_kernel_source(monkeypatch, tmp_path):
     for f in files:
         with open(f, 'rb') as fh:
             h.update(os.path.basename(f).encode() + b'\0' + fh.read())
-    assert tune.sources_sha() == h.hexdigest()[:16]
+    h.update(repr((build.FLAGS[:4], sorted((k, tuple(v)) for k, v in build.EXTRA_FLAGS.items()))).encode())
+    h.update(b'libpath ')
+    base = tune.sources_sha()
+    assert base == h.hexdigest()[:16]
+    assert not any('/' in f for f in build.FLAGS[:4])          # no path of this checkout in the stamp: the GPU box sees another root
+    assert _fresh_tune(monkeypatch, CY_LIBPATH='/somewhere/else.so').sources_sha() != base
+    monkeypatch.delenv('CY_LIBPATH')
+    monkeypatch.setattr(build, 'EXTRA_FLAGS', {k: list(v) + ['-fno-slp-vectorize'] for k, v in build.EXTRA_FLAGS.items()})
+    assert importlib.reload(tune).sources_sha() != base

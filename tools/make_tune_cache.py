@@ -62,7 +62,8 @@ def main():
     cases = [('train', 'f16', 16, 608, False), ('train', 'f16', 16, 608, True)]
     if not quick:
         cases += [('train', 'bf16', 16, 608, False), ('train', 'bf16', 16, 608, True), ('eval', 'f16', 32, 608, False),
-                  ('train', 'f16', 8, 1024, False), ('train', 'f16', 16, 1216, False), ('train', 'f32', 16, 608, True)]
+                  ('train', 'f16', 8, 1024, False), ('train', 'f16', 16, 1216, False), ('train', 'f32', 16, 608, True),
+                  ('train', 'f32', 16, 608, False)]      # (f32 default mode: bench.py's other_configs.train608_f32)
         # multiscale training (reference kitti_dataset.py:42-43,225-230: img_size +- 3 x 32 every 10 batches): without these a
         # new resolution times its candidates at first sight
         cases += [('train', 'f16', 16, S, False) for S in (512, 544, 576, 640, 672, 704)]
