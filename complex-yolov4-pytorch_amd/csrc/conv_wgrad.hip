@@ -257,6 +257,197 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// BatchNorm backward + weight gradient of a conv WITHOUT an input gradient (the first layer) in ONE kernel.
+// That layer's pre-BN gradient dRaw has a single reader, its own weight gradient -- and at 608 x 608 x 32 channels it is the
+// largest tensor of the step (378 MB at batch 16): the separate passes write it (cy_bn_act_bwd_apply_fused: read g + raw, write
+// dRaw) and read it back (cy_conv_wgrad), the last two kernels of backward, on the critical path in front of the optimizer
+// (profiles/r06_timeline: 238 + 158 us).  Here the register-staged kernel above applies
+//     dRaw = scale * (g * act'(raw * scale + shift) - mean(dz) - xhat * mean(dz * xhat))
+// to the (g, raw) chunks it has just loaded, rounds to the storage type exactly as the apply pass does, and writes the result
+// into its LDS tile instead of memory: dRaw never exists.  Prologue as cy_bn_act_bwd_apply_fused: fold of the CY_STAT_BINS sum
+// bins (double, bin order), the BatchNorm parameter gradients (first block), zeroing of the other table of the pair.
+struct WgradBnParams {
+    const unsigned char* raw;     // the layer's pre-BN tensor, same pixels as dy
+    int ldraw;
+    const float* mean;
+    const float* invstd;
+    const float* scale;
+    const float* shift;
+    const float* bins;            // [CY_STAT_BINS][2][Co]: sum dz, sum dz * xhat
+    float* ggamma;
+    float* gbeta;
+    float gscale;
+    float* zero_table;
+    int zero_n;
+};
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) wgrad_bn_kernel(const WgradParams p, const WgradBnParams f) {
+    constexpr int CH = 8, BKP = 64, BCO = 32, BCI = 128;
+    constexpr int CPR_A = BCO / CH, RPP_A = 256 / CPR_A, PASS_A = BKP / RPP_A;      // 4 chunks per row, 64 rows per pass, 1 pass
+    constexpr int CPR_B = BCI / CH, RPP_B = 256 / CPR_B, PASS_B = BKP / RPP_B;
+    constexpr int RB_A = BCO * 2 + 32, RB_B = BCI * 2 + 32;
+    constexpr int STAGE = BKP * (RB_A + RB_B);
+    constexpr int TI = BCO / 32, TJ = BCI / 32;
+    static_assert(PASS_A == 1, "one dy / raw chunk per thread and K step");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float s_dg[BCO], s_db[BCO];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int ct = lid % p.ncol_tiles, sp = lid / p.ncol_tiles;      // one tile of output channels (Co <= 32)
+    const int col0 = ct * BCI, co0 = 0;
+    const int pix_begin = sp * p.pps;
+    const int pix_end = min(p.M, pix_begin + p.pps);
+
+    // ---- BatchNorm-backward fold (every block needs the two means; the first one also owns the parameter gradients) ----
+    if (tid < BCO) {
+        double s1 = 0.0, s2 = 0.0;
+        if (tid < p.Co) {
+#pragma unroll
+            for (int b = 0; b < CY_STAT_BINS; ++b) {
+                s1 += (double)f.bins[((size_t)b * 2) * p.Co + tid];
+                s2 += (double)f.bins[((size_t)b * 2 + 1) * p.Co + tid];
+            }
+            if (lid == 0) {
+                if (f.gbeta) f.gbeta[tid] += f.gscale * (float)s1;
+                if (f.ggamma) f.ggamma[tid] += f.gscale * (float)s2;
+            }
+        }
+        s_db[tid] = (float)s1;
+        s_dg[tid] = (float)s2;
+    }
+    for (int i = blockIdx.x * 256 + tid; i < f.zero_n; i += gridDim.x * 256) f.zero_table[i] = 0.f;
+    __syncthreads();
+
+    const int a_chunk = tid % CPR_A, a_row0 = tid / CPR_A;
+    const int b_chunk = tid % CPR_B, b_row0 = tid / CPR_B;
+    const int a_co = co0 + a_chunk * CH;
+    const bool a_cok = a_co < p.Co;        // Co is a multiple of CH
+    float sc[CH], sh[CH], mu[CH], is[CH], mg[CH], mb[CH];
+    {
+        const float invM = 1.f / (float)p.M;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = min(a_co + i, p.Co - 1);
+            sc[i] = f.scale[c]; sh[i] = f.shift[c]; mu[i] = f.mean[c]; is[i] = f.invstd[c];
+            mg[i] = s_dg[min(a_chunk * CH + i, BCO - 1)] * invM; mb[i] = s_db[min(a_chunk * CH + i, BCO - 1)] * invM;
+        }
+    }
+    const int b_col = col0 + b_chunk * CH;
+    const bool b_cok = b_col < p.Ncols;
+    const int b_tap = b_cok ? b_col / p.Ci : 0;
+    const int b_ci = b_col - b_tap * p.Ci;
+    const int b_kh = b_tap / p.ks, b_kw = b_tap - b_kh * p.ks;
+    int bn[PASS_B], boh[PASS_B], bow[PASS_B];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int q = 0; q < PASS_B; ++q) {
+        const int m = pix_begin + b_row0 + q * RPP_B;
+        const int n = m / ohw, rem = m - n * ohw;
+        bn[q] = n; boh[q] = rem / p.OW; bow[q] = rem - boh[q] * p.OW;
+    }
+
+    u32x4 gv, rv, bv[PASS_B];
+    bool a_ok = false;
+    auto load_tile = [&](int pix0) {
+        const int m = pix0 + a_row0;
+        a_ok = a_cok && m < pix_end;
+        gv = u32x4{0u, 0u, 0u, 0u};
+        rv = gv;
+        if (a_ok) {
+            gv = *reinterpret_cast<const u32x4*>(p.dy + ((size_t)m * p.lddy + a_co) * sizeof(T));
+            rv = *reinterpret_cast<const u32x4*>(f.raw + ((size_t)m * f.ldraw + a_co) * sizeof(T));
+        }
+#pragma unroll
+        for (int q = 0; q < PASS_B; ++q) {
+            const int mq = pix0 + b_row0 + q * RPP_B;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int xh = boh[q] * p.stride - p.pad + b_kh, xw = bow[q] * p.stride - p.pad + b_kw;
+            if (b_cok && mq < pix_end && xh >= 0 && xh < p.XH && xw >= 0 && xw < p.XW) {
+                const size_t off = ((size_t)((bn[q] * p.XH + xh) * p.XW + xw) * p.ldx + b_ci) * sizeof(T);
+                v = *reinterpret_cast<const u32x4*>(p.x + off);
+            }
+            bv[q] = v;
+            bow[q] += BKP;
+            while (bow[q] >= p.OW) { bow[q] -= p.OW; ++boh[q]; }
+            while (boh[q] >= p.OH) { boh[q] -= p.OH; ++bn[q]; }
+        }
+    };
+    auto store_tile = [&](int stage) {
+        unsigned char* as = smem + stage * STAGE;
+        unsigned char* bs = as + BKP * RB_A;
+        // the BatchNorm backward of this thread's 8 channels of one pixel (cy_bn_act_bwd_apply_fused's arithmetic, rounded to
+        // the storage type like the tensor it replaces); rows outside the split contribute zeros
+        u32x4 dv = {0u, 0u, 0u, 0u};
+        if (a_ok) {
+            float fv[CH], g[CH], o[CH];
+            chunk_to_f32<T>(rv, fv);
+            chunk_to_f32<T>(gv, g);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const float dz = g[i] * act_grad<ACT, true>(fv[i] * sc[i] + sh[i]);
+                const float xh = (fv[i] - mu[i]) * is[i];
+                o[i] = sc[i] * (dz - mb[i] - xh * mg[i]);
+            }
+            dv = f32_to_chunk<T>(o);
+        }
+        *reinterpret_cast<u32x4*>(as + a_row0 * RB_A + a_chunk * 16) = dv;
+#pragma unroll
+        for (int q = 0; q < PASS_B; ++q)
+            *reinterpret_cast<u32x4*>(bs + (b_row0 + q * RPP_B) * RB_B + b_chunk * 16) = bv[q];
+    };
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = pix_end > pix_begin ? (pix_end - pix_begin + BKP - 1) / BKP : 0;
+    if (nkt > 0) {
+        load_tile(pix_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int q16 = lane & 15, g = lane >> 4;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(pix_begin + (kt + 1) * BKP);
+        const unsigned char* as = smem + cur * STAGE;
+        const unsigned char* bs = as + BKP * RB_A;
+#pragma unroll
+        for (int kk = 0; kk < BKP / 32; ++kk) {
+            typename WMma<T>::frag a[TI], b[TJ];
+            const int prow = kk * 32 + g * 8 + (q16 >> 2);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const unsigned char* ptr = as + prow * RB_A + ((wi * (BCO / 2) + i * 16 + ((q16 & 3) << 2)) << 1);
+                a[i] = tr16_pair<T>(ptr, ptr + 4 * RB_A);
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const unsigned char* ptr = bs + prow * RB_B + ((wj * (BCI / 2) + j * 16 + ((q16 & 3) << 2)) << 1);
+                b[j] = tr16_pair<T>(ptr, ptr + 4 * RB_B);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = WMma<T>::mma(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    wgrad_store<TI, TJ, BCO, BCI>(p, acc, sp, co0, col0, wi, wj, q16, g);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // f16 weight gradient with direct-to-LDS tiles (the default f16 path; the register-staged kernel above stays for f32,
 // for the scalar-gather check of the transpose-read mapping and for offsets beyond 32 bits).
 //
@@ -760,6 +951,42 @@ extern "C" int cy_conv_wgrad(const void* dy, int N, int OH, int OW, int Co, int 
     }
     if (dtype == CY_BF16) return use_tr ? dispatch<bf16, true>(p, split, cy_s(s)) : dispatch<bf16, false>(p, split, cy_s(s));
     return use_tr ? dispatch<f16, true>(p, split, cy_s(s)) : dispatch<f16, false>(p, split, cy_s(s));
+}
+
+extern "C" int cy_conv_wgrad_bn(const void* g, int N, int OH, int OW, int Co, int ldg, const void* raw, int ldraw, const void* x,
+                                int XH, int XW, int Ci, int ldx, int ks, int stride, int pad, int dtype, const float* mean,
+                                const float* invstd, const float* scale, const float* shift, const float* part_bins, int rows,
+                                float* ggamma, float* gbeta, float gscale, float* zero_table, int zero_n, int act, float* part,
+                                int split, cy_stream_t s) {
+    CY_ENTER();
+    if (!g || !raw || !x || !part || !mean || !invstd || !scale || !shift || !part_bins || split < 1 || rows != CY_STAT_BINS ||
+        (zero_n > 0 && !zero_table) || zero_table == part_bins)
+        return CY_ERR_ARG;
+    if (dtype != CY_F16 && dtype != CY_BF16) return CY_ERR_UNSUPPORTED;
+    if (Co % 8 || Co > 32 || Ci % 8 || ldg % 8 || ldraw % 8 || ldx % 8 || ks < 1 || ks > 3) return CY_ERR_UNSUPPORTED;
+    WgradParams p;
+    p.dy = (const unsigned char*)g; p.x = (const unsigned char*)x; p.part = part;
+    p.N = N; p.OH = OH; p.OW = OW; p.Co = Co; p.lddy = ldg;
+    p.XH = XH; p.XW = XW; p.Ci = Ci; p.ldx = ldx; p.ks = ks; p.stride = stride; p.pad = pad;
+    p.M = N * OH * OW; p.Ncols = ks * ks * Ci; p.CoRows = Co;
+    p.pps = (((p.M + split - 1) / split) + 63) / 64 * 64;
+    p.x_bytes = 0; p.atomic = 0;
+    p.ncol_tiles = (p.Ncols + 127) / 128; p.nco_tiles = 1;
+    WgradBnParams f;
+    f.raw = (const unsigned char*)raw; f.ldraw = ldraw; f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
+    f.bins = part_bins; f.ggamma = ggamma; f.gbeta = gbeta; f.gscale = gscale; f.zero_table = zero_table; f.zero_n = zero_n;
+    constexpr int smem = 2 * 64 * ((32 * 2 + 32) + (128 * 2 + 32));
+    const dim3 grid((unsigned)(p.ncol_tiles * split));
+#define CY_WBN(T, A) hipLaunchKernelGGL((wgrad_bn_kernel<T, A>), grid, dim3(256), smem, cy_s(s), p, f);
+#define CY_WBN_ACT(T)                                        \
+    if (act == CY_ACT_MISH) { CY_WBN(T, CY_ACT_MISH) }       \
+    else if (act == CY_ACT_LEAKY) { CY_WBN(T, CY_ACT_LEAKY) } \
+    else { CY_WBN(T, CY_ACT_LINEAR) }
+    if (dtype == CY_F16) { CY_WBN_ACT(f16) } else { CY_WBN_ACT(bf16) }
+#undef CY_WBN
+#undef CY_WBN_ACT
+    CY_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int cy_wgrad_reduce(const float* part, int split, int CoRows, int CiPad, int ks, int Co, int Ci, float scale,

@@ -189,6 +189,9 @@ class Engine:
         # pin_retired before its first capture.  (a caller whose parameter / gradient tensors move every epoch --
         # EMA swaps, load_state_dict(assign=True) -- used to leak a table per move for the engine's lifetime.)
         self.pin_retired = False
+        # the first layer's BatchNorm backward inside its weight-gradient kernel (ops.conv_wgrad_bn; CY_FIRST_FUSED=0: two launches)
+        self._first_fused = (training and getattr(device, 'type', str(device)) == 'cuda' and dt != CY_F32
+                             and hasattr(ops, 'conv_wgrad_bn') and os.environ.get('CY_FIRST_FUSED', '1') != '0')
         self._wgrad_ev, self._main_stream, self._side_scope = {}, None, None
         self._main_h = self._side_h = None      # raw stream handles of the pass under way (ops.stream_handle)
         self._fork_ev = self._join_ev = None    # ops.Event: main -> side before a fold, side -> main at the end of backward
@@ -812,6 +815,14 @@ class Engine:
                 self.wsplit[idx] = memo[key] - 1000
             else:
                 self.wsplit[idx] = memo[key]
+        for rec in self.plan.convs:
+            if self._first_fused_rec(rec):
+                # its own kernel (register-staged, 256-thread blocks over 64-pixel steps, HBM-bound on g + raw): as many pixel
+                # splits as the slab region holds, up to four blocks per compute unit -- 128 blocks ran at 2.6 TB/s
+                idx = rec['idx']
+                self.wsplit[idx] = max(1, min(self.wsplit_cap[idx], 1024))
+                self.wtile64.discard(idx)
+                self.watomic.pop(idx, None)
         if self.watomic:
             self.wpart.zero_()        # atomic slabs start from zero (the timing launches added into them); the folds keep them so
         self._reduce_groups = None
@@ -1047,6 +1058,37 @@ class Engine:
             return
         self._wgrad_launch(rec, dy, xv)
 
+    def _first_fused_rec(self, rec):
+        """Does this conv's backward run as ONE kernel (BatchNorm backward inside the weight gradient, ops.conv_wgrad_bn)?  A
+        BatchNorm conv without an input gradient and without a folded shortcut, at most 32 output channels: the first layer."""
+        return (self._first_fused and self.fused_bn and rec['first'] and rec['bn'] and rec.get('res') is None
+                and rec['cout'] <= 32 and rec['cout'] % 8 == 0)
+
+    def _wgrad_bn(self, rec, raw, g, tbl, rows, other, act):
+        idx = rec['idx']
+        _, bname = self._names(rec)
+        vec = self.bnvec[idx]
+        cop, cip = _wgrad_rows(rec), rec['cin_pad']
+        sp = self.wsplit[idx]
+        off = self.wslab_off[idx]
+        part = self.wpart[off:off + sp * cop * rec['ks'] * rec['ks'] * cip]
+
+        def launch():
+            with ops.prof('wgrad', *self._conv_work(rec)):
+                ops.conv_wgrad_bn(g, raw, self.view(rec['x']), rec['ks'], rec['stride'], rec['pad'], vec[0], vec[1], vec[2], vec[3],
+                                  tbl, rows, self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls, other, act,
+                                  part, sp)
+        if self.side is not None:
+            ev = self._wgrad_ev.get(idx)
+            if ev is None:
+                ev = self._wgrad_ev[idx] = ops.Event()
+            ops.event_record(ev, self._main_h)
+            ops.stream_wait_event(self._side_h, ev)
+            with self._side_scope:
+                launch()
+            return
+        launch()
+
     def _wgrad_launch(self, rec, dy, xv):
         idx = rec['idx']
         cname, _ = self._names(rec)
@@ -1117,6 +1159,12 @@ class Engine:
             res = rec['res']
             for ref, acc in runs:
                 ops.slice_copy(g.channels(ref.c0 - res.c0, ref.C), self.view(ref, grad=True), accumulate=acc)
+        if self._first_fused_rec(rec) and not b['dx'] and not runs:
+            # a conv block without an input gradient (the first layer): nothing but its own weight gradient reads dRaw -- the
+            # BatchNorm backward is applied inside the weight-gradient kernel and the 378 MB tensor is neither written nor read
+            # back (cy_conv_wgrad_bn); on the weight-gradient stream, like every weight gradient
+            self._wgrad_bn(rec, raw, g, tbl, rows, other, act)
+            return
         if self.fused_bn:
             ops.bn_act_bwd_apply_fused(raw, g, g, res_view, res_acc, mean, invstd, scale, shift, tbl, rows,
                                        self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls, other, act)

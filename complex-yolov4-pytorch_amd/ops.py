@@ -464,6 +464,15 @@ def conv_wgrad(dy, x, ks, stride, pad, part, split, use_tr=1, atomic=False, tile
                dy.dt, _p(part), split, use_tr | (4 if atomic else 0) | (8 if tile64 else 0), _stream())
 
 
+def conv_wgrad_bn(g, raw, x, ks, stride, pad, mean, invstd, scale, shift, bins, rows, ggamma, gbeta, gscale, zero_table, act, part, split):
+    """BatchNorm backward + weight gradient of a conv without an input gradient in one kernel (cy_conv_wgrad_bn): the pre-BN
+    gradient is never written.  Raises CyoloError(CY_ERR_UNSUPPORTED) where the kernel does not apply."""
+    _require_gpu()
+    lib().call('cy_conv_wgrad_bn', _p(g), g.N, g.H, g.W, g.C, g.ld, _p(raw), raw.ld, _p(x), x.H, x.W, x.C, x.ld, ks, stride, pad,
+               g.dt, _p(mean), _p(invstd), _p(scale), _p(shift), _p(bins), rows, _p(ggamma), _p(gbeta), float(gscale), _p(zero_table),
+               zero_table.numel() if zero_table is not None else 0, act, _p(part), split, _stream())
+
+
 def wgrad_reduce(part, split, co_rows, ci_pad, ks, Co, Ci, scale, accumulate, grad):
     lib().call('cy_wgrad_reduce', _p(part), split, co_rows, ci_pad, ks, Co, Ci, float(scale), int(accumulate), _p(grad),
                _stream())

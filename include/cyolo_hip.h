@@ -212,6 +212,20 @@ int cy_conv_stats_rows_det(int M, int OC);
 /* Extra rows a partial table needs behind it (0 since the binned-atomics version; kept for ABI stability). */
 int cy_bn_scratch_rows(void);
 
+/* BatchNorm backward + weight gradient in ONE kernel, for a conv block WITHOUT an input gradient (the first layer: reference
+ * darknet2pytorch.py:247-278, module 0 -- autograd never asks for d(loss)/d(image)).  Equivalent to cy_bn_act_bwd_apply_fused
+ * (no shortcut operand, dx NOT written) followed by cy_conv_wgrad on the dRaw that pass would have stored: g = dL/d(activated
+ * output), raw = the layer's pre-BN tensor, part_bins = the [16][2][Co] table of (sum dz, sum dz * xhat) (cy_bn_act_bwd_reduce or
+ * cy_conv_dgrad_bn_sums), mean / invstd / scale / shift = the layer's batch statistics and affine.  Adds gscale * sums into
+ * ggamma / gbeta (NULL: skipped), zeroes zero_table (the other table of the alternating pair), and writes `split` slabs
+ * part[sp][Co][ks*ks*Ci] like cy_conv_wgrad.  dRaw is formed in registers (rounded to `dtype` as the stored tensor would be) and
+ * goes straight into the kernel's LDS tile: 378 MB less written and read again at 608 x 608 x 32 channels, batch 16.
+ * 16-bit dtypes, Co <= 32 and a multiple of 8; anything else returns CY_ERR_UNSUPPORTED (the caller keeps the two launches). */
+int cy_conv_wgrad_bn(const void* g, int N, int OH, int OW, int Co, int ldg, const void* raw, int ldraw, const void* x, int XH,
+                     int XW, int Ci, int ldx, int ks, int stride, int pad, int dtype, const float* mean, const float* invstd,
+                     const float* scale, const float* shift, const float* part_bins, int rows, float* ggamma, float* gbeta,
+                     float gscale, float* zero_table, int zero_n, int act, float* part, int split, cy_stream_t s);
+
 /* Weight gradient: part[sp][CoRows][ks*ks*Ci] = sum over the pixels of split sp of dy[p][co] * x[p (+) tap][ci].
  * dy: view (N,OH,OW,Co,lddy) ; x: view (N,XH,XW,Ci,ldx).  `split` partial slabs are written (not accumulated);
  * cy_wgrad_reduce folds them into the torch-layout gradient.

@@ -318,3 +318,53 @@ def test_packed_f32_head_kernels_beside_mfma_reproducer():
     packed = _beside(slp_loss, lambda: dl, ag, 3000)
     print('cy_yolo_loss beside igemm_fast<192,128>: shipped build %d / 2999 repeats differ, SLP (packed f32) build %d / 2999' % (shipped, packed))
     assert shipped == 0
+
+
+@pytest.mark.parametrize('dt', [CY_F16, CY_BF16])
+@pytest.mark.parametrize('case', [(2, 8, 32, 3, 1, 64, 40, 'mish'), (3, 8, 16, 3, 1, 37, 21, 'leaky'), (16, 8, 32, 3, 1, 152, 152, 'mish'),
+                                  (2, 16, 16, 1, 1, 30, 50, 'linear')])
+def test_wgrad_with_bn_backward_inside(dt, case):
+    """cy_conv_wgrad_bn (BatchNorm backward applied to (g, raw) inside the weight-gradient kernel: the first layer's pre-BN
+    gradient is never stored) = cy_bn_act_bwd_apply_fused followed by cy_conv_wgrad: the folded weight gradient within the
+    rounding of one storage ulp of dRaw (the two kernels may contract their float32 expressions differently), the BatchNorm
+    parameter gradients and the zeroed table exactly."""
+    N, Ci, Co, ks, st, H, W, act = case
+    pad = (ks - 1) // 2
+    g = torch.Generator().manual_seed(N * 7 + Co + H)
+    tdt = ops.torch_dtype(dt)
+    x = View.alloc(N, H, W, Ci, dt); x.buf.copy_(torch.randn(x.buf.numel(), generator=g).to(tdt))
+    raw = View.alloc(N, H, W, Co, dt, ld=Co + 8); raw.buf.copy_(torch.randn(raw.buf.numel(), generator=g).to(tdt))
+    gy = View.alloc(N, H, W, Co, dt); gy.buf.copy_(torch.randn(gy.buf.numel(), generator=g).to(tdt))
+    M = N * H * W
+    vec = torch.stack([torch.randn(Co, generator=g) * 0.1, torch.rand(Co, generator=g) + 0.5, torch.rand(Co, generator=g) + 0.5,
+                       torch.randn(Co, generator=g) * 0.2]).to(DEV)
+    a = ops.ACT[act]
+    rows = ops.bn_bwd_rows(M, Co, dt)
+    bins = torch.zeros(rows, 2, Co, device=DEV)
+    ops.bn_act_bwd_reduce(raw, gy, vec[0], vec[1], vec[2], vec[3], a, bins, rows)
+    split = 5
+    # the two launches
+    gg1, gb1 = torch.ones(Co, device=DEV), torch.ones(Co, device=DEV)
+    other1 = torch.ones(rows * 2 * Co, device=DEV)
+    draw = View.alloc(N, H, W, Co, dt)
+    ops.bn_act_bwd_apply_fused(raw, gy, draw, None, False, vec[0], vec[1], vec[2], vec[3], bins, rows, gg1, gb1, 0.5, other1, a)
+    part1 = torch.full((split, Co, ks * ks * Ci), float('nan'), device=DEV)
+    ops.conv_wgrad(draw, x, ks, st, pad, part1, split)
+    # one launch
+    gg2, gb2 = torch.ones(Co, device=DEV), torch.ones(Co, device=DEV)
+    other2 = torch.ones(rows * 2 * Co, device=DEV)
+    part2 = torch.full((split, Co, ks * ks * Ci), float('nan'), device=DEV)
+    ops.conv_wgrad_bn(gy, raw, x, ks, st, pad, vec[0], vec[1], vec[2], vec[3], bins, rows, gg2, gb2, 0.5, other2, a, part2, split)
+    assert torch.equal(gg2, gg1) and torch.equal(gb2, gb1)
+    assert float(other2.abs().max()) == 0.0 and float(other1.abs().max()) == 0.0
+    w1, w2 = part1.double().sum(0), part2.double().sum(0)
+    assert torch.isfinite(w2).all()
+    scale = float(w1.abs().max()) + 1e-6
+    # dRaw elements are O(1), rounded to 2^-11 (f16) / 2^-8 (bf16) relative; a flipped rounding of one element moves a sum by that
+    tol = (2 ** -7 if dt == CY_BF16 else 2 ** -10) * 4
+    assert float((w1 - w2).abs().max()) <= tol * max(1.0, scale ** 0.5), (float((w1 - w2).abs().max()), scale)
+    # and against float64 torch on the stored dRaw of the two-launch path
+    dr = draw.to_nchw().double().cpu()
+    ref = torch.nn.grad.conv2d_weight(x.to_nchw().double().cpu()[:, :Ci], (Co, Ci, ks, ks), dr, st, pad)
+    got = w2.view(Co, ks, ks, Ci).permute(0, 3, 1, 2).cpu()
+    torch.testing.assert_close(got, ref, rtol=2e-2 if dt == CY_BF16 else 4e-3, atol=(2e-2 if dt == CY_BF16 else 4e-3) * float(ref.abs().max()))
