@@ -75,8 +75,13 @@ def test_train_step_f32_parity(golden, tag, cfg, B, S, mode):
 
 
 @pytest.mark.parametrize('tag,cfg,B,S', CASES)
-def test_train_step_f16_band(golden, tag, cfg, B, S):
-    """Performance mode (fp16 storage, fp32 accumulate): stated band, not the fp32 tolerance."""
+def test_train_step_f16_band(golden, monkeypatch, tag, cfg, B, S):
+    """Performance mode (fp16 storage, fp32 accumulate): stated band, not the fp32 tolerance.  The kernels are the library's
+    shape-only defaults (no per-layer timing): these small shapes are not in the persisted tune table, a timed choice differs from
+    run to run, and on the batch-1 random-init net a different summation order moves the loss by ~1 % (ten runs on the MI355X,
+    round 6: 0.1-1.2 %) -- the band is about fp16 storage, not about which tile the tuner happened to crown."""
+    monkeypatch.setenv('CY_CONV_AUTOTUNE', '0')
+    monkeypatch.setenv('CY_WGRAD_AUTOTUNE', '0')
     g = golden('darknet')
     model = _model(cfg, True, 'f16')
     model.train()
