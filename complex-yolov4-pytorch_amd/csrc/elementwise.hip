@@ -146,7 +146,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
 // kernel that reads it (other blocks may still be reading), so two tables alternate from one BatchNorm layer to the next
 // and every launch zeroes the OTHER one (last read by the previous layer's kernel, next written by the following conv).
 struct BnFoldParams {
-    const float* bins;       // [CY_STAT_BINS][2][C]
+    const float* bins;       // [CY_STAT_BINS][2][bins_ld], this layer's channels from column bins_c0 (a fused conv of two sibling
+                             // layers leaves ONE table of Ca + Cb channels: cy_bn_act_fwd_fused's stats_ld / stats_c0)
+    int bins_ld, bins_c0;
     float* zero_table;       // the other table of the pair
     int zero_n;
     double count;
@@ -177,8 +179,8 @@ __global__ void __launch_bounds__(256) bn_act_fwd_fused_kernel(const T* __restri
         double s = 0.0, q = 0.0;
 #pragma unroll
         for (int b = 0; b < CY_STAT_BINS; ++b) {
-            s += (double)f.bins[((size_t)b * 2) * C + c];
-            q += (double)f.bins[((size_t)b * 2 + 1) * C + c];
+            s += (double)f.bins[((size_t)b * 2) * f.bins_ld + f.bins_c0 + c];
+            q += (double)f.bins[((size_t)b * 2 + 1) * f.bins_ld + f.bins_c0 + c];
         }
         const double m = s / f.count;
         double var = q / f.count - m * m;
@@ -758,7 +760,10 @@ __device__ __forceinline__ void pack_tile(const cy_pack_desc& d, int tile, T* ld
                 T v[CH];
 #pragma unroll
                 for (int e = 0; e < CH; ++e) v[e] = lds[(cc * CH + e) * ROW + tap * 64 + ci_l];
-                *reinterpret_cast<u32x4*>(wd + ((long)ci * kk + tap) * d.CoPad + co) = *reinterpret_cast<const u32x4*>(v);
+                // (wd_ld: row stride of the dgrad matrix when this layer fills a column range of a WIDER one -- two sibling 1x1
+                // layers packed side by side, [ci][Ca + Cb]; 0 = its own kk * CoPad)
+                *reinterpret_cast<u32x4*>(wd + (d.wd_ld > 0 ? (long)ci * d.wd_ld + (long)tap * d.CoPad : ((long)ci * kk + tap) * d.CoPad) + co) =
+                    *reinterpret_cast<const u32x4*>(v);
             }
         }
     }
@@ -997,7 +1002,7 @@ extern "C" int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, con
                                    const float* stats_bins, int rows, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                    float eps, float* vec_out, float* zero_table, int zero_n, int act, int dtype,
-                                   cy_stream_t s) {
+                                   int stats_ld, int stats_c0, cy_stream_t s) {
     CY_ENTER();
     const int ch = dtype == CY_F32 ? 4 : 8;
     if (!x || !y || !stats_bins || !gamma || !beta || !vec_out || rows != CY_BINS || M < 1 || C % ch || ldx % ch || ldy % ch ||
@@ -1014,6 +1019,8 @@ extern "C" int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, con
     f.bins = stats_bins; f.zero_table = zero_table; f.zero_n = zero_n; f.count = (double)M; f.gamma = gamma; f.beta = beta;
     f.rmean = running_mean; f.rvar = running_var; f.nbt = (long long*)num_batches_tracked; f.momentum = momentum; f.eps = eps;
     f.vec = vec_out;
+    f.bins_ld = stats_ld > 0 ? stats_ld : C; f.bins_c0 = stats_ld > 0 ? stats_c0 : 0;
+    if (f.bins_c0 < 0 || f.bins_c0 + C > f.bins_ld) return CY_ERR_ARG;
 #define CY_BNFF(T, A)                                                                                                  \
     if (res) hipLaunchKernelGGL((bn_act_fwd_fused_kernel<T, A, true>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (T*)y, \
                                 ldy, (const T*)res, ldres, (long)M, C, cg, f, (int)ppb);                                \

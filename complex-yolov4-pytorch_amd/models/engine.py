@@ -105,6 +105,16 @@ class Engine:
         self._dgrad_sums, self._sums_fused = {}, set()      # (P idx, run c0) -> (L record, tile hint);  {L idx}
         self.tdt = ops.torch_dtype(dt)
         self.act, self.gact = {}, {}
+        # Sibling 1x1 convs over ONE input (the two branches of every CSP stage, reference cfg complex_yolov4.cfg:44-64,124,212,421,
+        # 635) as one launch each for the forward conv, the weight gradient and the input gradient (round 6): lead conv idx ->
+        # pair record, follower idx -> lead idx.  Training engines of the default 16-bit mode only; see _find_siblings.
+        self._sib, self._sib_follow = {}, {}
+        self._views, self._view_refs = {}, []
+        sf = os.environ.get('CY_SIBLING_FUSE', '1')      # 0: off; 1: the 16-bit modes; 2: the fp32 default mode too (tests: the CPU simulator)
+        if (training and (dt != CY_F32 or sf == '2') and not deterministic and hasattr(ops, 'bn_act_fwd_fused')
+                and os.environ.get('CY_FUSED_BN', '1') != '0' and sf != '0'):
+            self._find_siblings(plan)
+        sib_raw = {r['raw'].st.sid for pr in self._sib.values() for r in (pr['a'], pr['b'])}
         max_raw = 0
         for st in plan.storages:
             n = N * st.H * st.W * st.C
@@ -112,7 +122,8 @@ class Engine:
                 self.act[st.sid] = new('act %r' % (st,), n, torch.float32)
             elif st.kind == 'raw':
                 if training:
-                    self.act[st.sid] = new('raw %r' % (st,), n, self.tdt)
+                    if st.sid not in sib_raw:      # (a sibling pair's two pre-BN tensors are slices of ONE joint buffer, below)
+                        self.act[st.sid] = new('raw %r' % (st,), n, self.tdt)
                 else:
                     max_raw = max(max_raw, n)
             else:
@@ -120,6 +131,18 @@ class Engine:
                 if training and st.kind == 'act':
                     self.gact[st.sid] = new('gact %r' % (st,), n, self.tdt)
         self.raw_scratch = new('raw_scratch', max(max_raw, 1), self.tdt)
+        for lead, pr in self._sib.items():
+            A, B, Ca, Cb = pr['a'], pr['b'], pr['Ca'], pr['Cb']
+            CJ, H, W = Ca + Cb, A['H'], A['W']
+            for nm in ('raw', 'draw'):      # [A | B]: the conv's output / the two BatchNorm backwards' output (dY of the fused wgrad / dgrad)
+                buf = new('%s siblings %d+%d' % (nm, A['idx'], B['idx']), N * H * W * CJ, self.tdt)
+                pr[nm] = (View(buf, 0, N, H, W, Ca, CJ, dt), View(buf, Ca, N, H, W, Cb, CJ, dt), View(buf, 0, N, H, W, CJ, CJ, dt))
+            for r, v in ((A, pr['raw'][0]), (B, pr['raw'][1])):
+                self._views[(id(r['raw']), False)] = v
+                self._view_refs.append(r['raw'])
+            pr['rec'] = dict(A, cout=CJ)          # the joint conv as the launch helpers see it (A's index, Ca + Cb output channels)
+            pr['rec'].pop('_work', None)
+            pr['rec'].pop('_names', None)
         # per-conv persistent BN vectors and packed weights; shared scratch for the reductions
         self.bnvec, self.wf, self.wd = {}, {}, {}
         max_stats = max_bnrows = max_c = 1
@@ -127,22 +150,35 @@ class Engine:
         self.wsplit, self.wslab_off, self.wsplit_cap = {}, {}, {}
         self.watomic = {}          # conv idx -> split-K factor of its ATOMIC weight-gradient launch (all splits add into ONE slab)
         self.wtile64 = set()       # conv idx whose weight gradient runs on 64 x 64 tiles (a quarter of the split-K slabs)
-        self._views, self._view_refs = {}, []
         self._wgrad_tuned = False
         for rec in plan.convs:
             C, M = rec['cout'], N * rec['H'] * rec['W']
             cop, cip = _pad32(C), rec['cin_pad']
             kk = rec['ks'] * rec['ks']
-            self.wf[rec['idx']] = new('wf[%d]' % rec['idx'], (cop, kk * cip), self.tdt)
-            self.wd[rec['idx']] = new('wd[%d]' % rec['idx'], (cip, kk * cop), self.tdt) if training and not rec['first'] else None
+            pr = self._sib.get(rec['idx'])
+            if pr is not None:
+                # one forward matrix [Ca + Cb][Cin] (A's rows, then B's) and one dgrad matrix [Cin][Ca + Cb] (each module packs its
+                # own rows / columns: cy_pack_desc.wd_ld); self.wd[lead] is the JOINT matrix the fused dgrad multiplies
+                CJ = pr['Ca'] + pr['Cb']
+                pr['wf'] = new('wf siblings %d' % rec['idx'], (CJ, cip), self.tdt)
+                pr['wd'] = new('wd siblings %d' % rec['idx'], (cip, CJ), self.tdt)
+                self.wf[rec['idx']], self.wf[pr['b']['idx']] = pr['wf'][:pr['Ca']], pr['wf'][pr['Ca']:]
+                self.wd[rec['idx']], self.wd[pr['b']['idx']] = pr['wd'], pr['wd'][:, pr['Ca']:]
+                max_stats = max(max_stats, ops.conv_stats_rows(M, CJ, self.det) * 2 * CJ)
+            elif rec['idx'] not in self._sib_follow:
+                self.wf[rec['idx']] = new('wf[%d]' % rec['idx'], (cop, kk * cip), self.tdt)
+                self.wd[rec['idx']] = new('wd[%d]' % rec['idx'], (cip, kk * cop), self.tdt) if training and not rec['first'] else None
             if rec['bn']:
                 self.bnvec[rec['idx']] = new('bnvec[%d]' % rec['idx'], (4, C), torch.float32)
                 max_stats = max(max_stats, ops.conv_stats_rows(M, C, self.det) * 2 * C)
                 max_c = max(max_c, C)
                 if training:
                     max_bnrows = max(max_bnrows, ops.bn_bwd_rows(M, C, dt, self.det) * 2 * C)
-            if training:
-                wr = _wgrad_rows(rec)
+            if training and rec['idx'] in self._sib_follow:
+                # its weight gradient is the lower rows of the lead's joint slab
+                self.wsplit[rec['idx']], self.wsplit_cap[rec['idx']], self.wslab_off[rec['idx']] = 0, 0, max_wpart
+            elif training:
+                wr = _wgrad_rows(rec) if pr is None else pr['Ca'] + pr['Cb']
                 sp = ops.wgrad_split(M, wr, cip, rec['ks'])
                 # room for the split autotuner (first backward) to move away from the heuristic's choice
                 cap = max(1, min((M + 511) // 512, max(2 * sp, sp + 4), 128))
@@ -266,6 +302,46 @@ class Engine:
         return out
 
     # ---- views -----------------------------------------------------------------------------------
+    def _find_siblings(self, plan):
+        """Pairs of 1x1 / stride-1 BatchNorm convs (A, B) that read the SAME tensor and sit next to each other in the forward
+        plan -- the `route -2` pattern of every CSP stage -- and whose backward ops are adjacent too (B's, then A's: B stores the
+        input gradient, A accumulates onto it).  For such a pair the conv of A runs over the joint weight matrix and writes both
+        pre-BN tensors ([A | B], one joint buffer), the two BatchNorm passes stay per module (separate parameters in the
+        reference's state dict), the two BatchNorm backwards write their dRaw into one joint buffer, and ONE weight gradient
+        and ONE input gradient (K = Ca + Cb, no fan-in read-add-store) follow."""
+        fwd = plan.fwd
+        bpos = {id(b['fwd']): i for i, b in enumerate(plan.bwd) if b['op'] == 'conv_bwd'}
+        for i in range(len(fwd) - 1):
+            A, B = fwd[i], fwd[i + 1]
+            if A['op'] != 'conv' or B['op'] != 'conv' or not (A['bn'] and B['bn']) or A['first'] or B['first']:
+                continue
+            if (A['ks'], A['stride'], A['pad'], B['ks'], B['stride'], B['pad']) != (1, 1, 0, 1, 1, 0):
+                continue
+            xa, xb = A['x'], B['x']
+            if xa.st is not xb.st or xa.c0 != xb.c0 or xa.C != xb.C or A['cout'] % 32 or B['cout'] % 32 or A['act'] != B['act']:
+                continue
+            if A['idx'] in self._sib_follow or A['idx'] in self._sib:
+                continue
+            ia, ib = bpos.get(id(A)), bpos.get(id(B))
+            if ia is None or ib is None or ia != ib + 1:
+                continue
+            bA, bB = plan.bwd[ia], plan.bwd[ib]
+            if len(bA['dx']) != 1 or len(bB['dx']) != 1:
+                continue
+            (ra, acc_a), (rb, acc_b) = bA['dx'][0], bB['dx'][0]
+            if acc_b or not acc_a or ra.st is not xa.st or (ra.c0, ra.C, rb.c0, rb.C) != (xa.c0, xa.C, xa.c0, xa.C):
+                continue
+            self._sib[A['idx']] = dict(a=A, b=B, Ca=A['cout'], Cb=B['cout'])
+            self._sib_follow[B['idx']] = A['idx']
+
+    def _pair(self, idx):
+        """-> (pair record, 0 for the lead | 1 for the follower) or (None, None)."""
+        pr = self._sib.get(idx)
+        if pr is not None:
+            return pr, 0
+        lead = self._sib_follow.get(idx)
+        return (self._sib[lead], 1) if lead is not None else (None, None)
+
     def view(self, ref, grad=False):
         # views are static (fixed storages): built once per (tensor reference, forward / gradient)
         key = (id(ref), grad)
@@ -412,7 +488,14 @@ class Engine:
                 # every recorded pass is keyed by the parameter addresses: none of them can be looked up again
                 self._fwd_progs.clear()
                 self._bwd_progs.clear()
-            items = [(w, self.wf[r['idx']], self.wd[r['idx']], _pad32(r['cout']), r['cin_pad']) for w, r in zip(ws, self.plan.convs)]
+            items = []
+            for w, r in zip(ws, self.plan.convs):
+                pr = self._sib.get(r['idx']) or self._sib.get(self._sib_follow.get(r['idx']))
+                if pr is None:
+                    items.append((w, self.wf[r['idx']], self.wd[r['idx']], _pad32(r['cout']), r['cin_pad']))
+                else:      # a sibling pair: its own rows of the joint forward matrix, its own COLUMNS of the joint dgrad matrix
+                    c0 = 0 if r is pr['a'] else pr['Ca']
+                    items.append((w, self.wf[r['idx']], pr['wd'][:, c0:c0 + r['cout']], r['cout'], r['cin_pad'], pr['Ca'] + pr['Cb']))
             self._pack_table = ops.make_pack_table(items, self.device)
             self._pack_key = key
             self._pack_epoch = None
@@ -441,17 +524,20 @@ class Engine:
         group cut by gradient count held 0.68 ms of slabs, exposed before the optimizer) -- so the groups are cut by slab
         bytes (a quarter of the total each) and the final group only holds the last layers, <= 8 MB of slabs."""
         recs = [b['fwd'] for b in self.plan.bwd if b['op'] in ('conv_bwd', 'head_conv_bwd')]
-        nbytes = [4 * self.wsplit[r['idx']] * _wgrad_rows(r) * r['ks'] * r['ks'] * r['cin_pad'] for r in recs]
+        jrows = lambda r: (self._sib[r['idx']]['Ca'] + self._sib[r['idx']]['Cb']) if r['idx'] in self._sib else _wgrad_rows(r)
+        nbytes = [4 * self.wsplit[r['idx']] * jrows(r) * r['ks'] * r['ks'] * r['cin_pad'] for r in recs]
         tail, acc = len(recs) - 1, nbytes[-1] if recs else 0
         while tail > 0 and acc + nbytes[tail - 1] <= (8 << 20):
             tail -= 1
             acc += nbytes[tail]
         target = max(1, sum(nbytes[:tail]) // 4)
         groups, cur, n = [], [], 0
+        while 0 < tail < len(recs) and recs[tail - 1]['idx'] in self._sib_follow:      # (never cut between a follower and its lead)
+            tail -= 1
         for i, rec in enumerate(recs[:tail]):
             cur.append(rec)
             n += nbytes[i]
-            if n >= target:
+            if n >= target and rec['idx'] not in self._sib_follow:
                 groups.append(cur); cur, n = [], 0
         if cur:
             groups.append(cur)
@@ -465,6 +551,18 @@ class Engine:
             items = []
             for rec in g:
                 idx = rec['idx']
+                pr, role = self._pair(idx)
+                if pr is not None:
+                    # rows [0, Ca) / [Ca, Ca + Cb) of the LEAD's joint slabs (row stride Ca + Cb): one descriptor per module.  (The
+                    # lead is the later of the two in backward order; the fold plan below keeps a pair inside one group.)
+                    lead = pr['a']['idx']
+                    cop, cip = pr['Ca'] + pr['Cb'], rec['cin_pad']
+                    sp, off = self.wsplit[lead], self.wslab_off[lead]
+                    r0 = 0 if role == 0 else pr['Ca']
+                    part = self.wpart[off + r0 * cip:off + sp * cop * cip]
+                    items.append((part, self.grads['models.%d.conv%d.weight' % (idx, rec['n'])], sp, cop, cip, 1,
+                                  rec['cout'], rec['cin'], 1 if lead in self.watomic else 0))
+                    continue
                 cop, cip, kk = _wgrad_rows(rec), rec['cin_pad'], rec['ks'] * rec['ks']
                 sp = self.wsplit[idx]
                 off = self.wslab_off[idx]
@@ -514,6 +612,24 @@ class Engine:
         vec = self.bnvec[idx]
         mean, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3]
         C, M = rec['cout'], raw.M
+        pr, role = self._pair(idx)
+        if pr is not None:
+            # sibling pair: the lead's launch convolves with the joint matrix and leaves ONE statistics table of Ca + Cb channels;
+            # each module's BatchNorm + activation pass reads its slice of it (and of the joint pre-BN buffer).  The tables
+            # alternate once per PAIR: both passes read table _sp and zero the other one.
+            tbl, other = self.stats_pair[self._sp], self.stats_pair[self._sp ^ 1]
+            CJ = pr['Ca'] + pr['Cb']
+            if role == 0:
+                with ops.prof('igemm', *self._conv_work(pr['rec'])):
+                    ops.conv_igemm(xv, pr['wf'], CJ, pr['raw'][2], 1, 1, 0, flags=CONV_STATS, stats=tbl, tile=self._fwd_tile.get(idx, 0))
+            else:
+                self._sp ^= 1
+            res = self.view(rec['res']) if rec['res'] is not None else None
+            ops.bn_act_fwd_fused(raw, self.view(rec['out']), res, tbl, ops.conv_stats_rows(M, CJ), P[bname + '.weight'],
+                                 P[bname + '.bias'], P[bname + '.running_mean'], P[bname + '.running_var'],
+                                 P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, vec, other, ops.ACT[rec['act']],
+                                 stats_ld=CJ, stats_c0=0 if role == 0 else pr['Ca'])
+            return
         if self.training and self.fused_bn:
             tbl, other = self.stats_pair[self._sp], self.stats_pair[self._sp ^ 1]
             self._sp ^= 1
@@ -764,6 +880,11 @@ class Engine:
             idx = rec['idx']
             cop, cip, kk = _wgrad_rows(rec), rec['cin_pad'], rec['ks'] * rec['ks']
             dy = self.head_tmp[heads[id(rec)]] if id(rec) in heads else self.view(rec['out'], grad=True)
+            pr, role = self._pair(idx)
+            if role == 1:
+                continue                  # (its weight gradient = rows of its sibling's joint launch)
+            if pr is not None:
+                dy, cop = pr['draw'][2], pr['Ca'] + pr['Cb']
             xv = self.view(rec['x'])
             key = ('wgrad', self.dt, dy.N, dy.H, dy.W, dy.C, dy.ld, xv.H, xv.W, xv.C, xv.ld, rec['ks'], rec['stride'], rec['pad'])
             if key not in memo:
@@ -915,11 +1036,16 @@ class Engine:
                 continue
             idx, cop = rec['idx'], _pad32(rec['cout'])
             xv = self.view(rec['x'])
+            pr, role = self._pair(idx)
+            if role == 1:
+                continue                  # (convolved by its sibling's launch)
             if self.training:
-                raw = self.view(rec['raw'])
+                raw, wf = self.view(rec['raw']), self.wf[idx]
+                if pr is not None:
+                    raw, wf, cop = pr['raw'][2], pr['wf'], pr['Ca'] + pr['Cb']
                 key = ('fwd', self.dt, self.det, xv.N, xv.H, xv.W, xv.C, xv.ld, raw.C, raw.ld, rec['ks'], rec['stride'])
                 self._fwd_tile[idx] = self._time_hints(key, lambda h: ops.conv_igemm(
-                    xv, self.wf[idx], cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=self._stat_flags, stats=self.stats,
+                    xv, wf, cop, raw, rec['ks'], rec['stride'], rec['pad'], flags=self._stat_flags, stats=self.stats,
                     tile=h), xv.C, raw.C, ks=rec['ks'], slab=_slab_shape(rec))
             else:
                 out = self.view(rec['out'])
@@ -947,7 +1073,7 @@ class Engine:
             idx, cop = rec['idx'], _pad32(rec['cout'])
             xv, raw, out = self.view(rec['x']), self.view(rec['raw']), self.view(rec['out'])
             res = self.view(rec['res']) if rec['res'] is not None else None
-            if xv.C % 64 or raw.C % 8:
+            if xv.C % 64 or raw.C % 8 or self._pair(idx)[0] is not None:
                 continue
             _, bname = self._names(rec)
             vec, act = self.bnvec[idx], ops.ACT[rec['act']]
@@ -999,7 +1125,13 @@ class Engine:
             rec = b['fwd']
             dy = self.head_tmp[heads[id(rec)]] if id(rec) in heads else self.view(rec['out'], grad=True)
             wd, x = self.wd[rec['idx']], rec['x']
-            for ri, (ref, acc) in enumerate(b['dx']):
+            pr, role = self._pair(rec['idx'])
+            if role == 1:
+                continue                  # (its input gradient is part of its sibling's joint launch)
+            runs = b['dx']
+            if pr is not None:
+                dy, runs = pr['draw'][2], [(b['dx'][0][0], False)]      # K = Ca + Cb, the ONE writer of the input gradient: a store
+            for ri, (ref, acc) in enumerate(runs):
                 r0 = ref.c0 - x.c0
                 gv = self.view(ref, grad=True)
                 flags = CONV_TRANSPOSED | (CONV_ACCUM if acc else 0)
@@ -1159,6 +1291,17 @@ class Engine:
             res = rec['res']
             for ref, acc in runs:
                 ops.slice_copy(g.channels(ref.c0 - res.c0, ref.C), self.view(ref, grad=True), accumulate=acc)
+        pr, role = self._pair(idx)
+        if pr is not None:
+            # sibling pair (backward order: the follower B first, then the lead A): each module's BatchNorm backward writes its
+            # dRaw into its slice of the joint buffer instead of in place; after A's, ONE weight gradient (dY = [A | B]) and ONE
+            # input gradient (K = Ca + Cb, a store: no fan-in read-add-store) run on the joint operands
+            ops.bn_act_bwd_apply_fused(raw, g, pr['draw'][role], res_view, res_acc, mean, invstd, scale, shift, tbl, rows,
+                                       self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls, other, act)
+            if role == 0:
+                self._wgrad(pr['rec'], pr['draw'][2], self.view(rec['x']))
+                self._dgrad(pr['rec'], pr['draw'][2], [(b['dx'][0][0], False)])
+            return
         if self._first_fused_rec(rec) and not b['dx'] and not runs:
             # a conv block without an input gradient (the first layer): nothing but its own weight gradient reads dRaw -- the
             # BatchNorm backward is applied inside the weight-gradient kernel and the 378 MB tensor is neither written nor read

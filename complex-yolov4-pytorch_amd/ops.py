@@ -281,9 +281,11 @@ def make_pack_table(items, device):
     """items: [(w fp32 [Co,Ci,k,k], wf, wd or None, CoPad, CiPad)] -> (desc bytes tensor, block table tensor, keepalive)."""
     import struct
     raw, counts = b'', []
-    for w, wf, wd, cop, cip in items:
+    for item in items:
+        w, wf, wd, cop, cip = item[:5]
+        wd_ld = int(item[5]) if len(item) > 5 else 0      # row stride of a wider dgrad matrix this layer fills a column range of
         Co, Ci, ks, _ = w.shape
-        raw += struct.pack('<QQQiiiiii', w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else 0, Co, Ci, ks, cop, cip, 0)
+        raw += struct.pack('<QQQiiiiii', w.data_ptr(), wf.data_ptr(), wd.data_ptr() if wd is not None else 0, Co, Ci, ks, cop, cip, wd_ld)
         assert ks <= 3
         counts.append(((cop + 63) // 64) * ((cip + 63) // 64) * MULTI_ELEMS)   # one block per 64 x 64 (co, ci) tile
     desc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
@@ -493,12 +495,12 @@ def bn_act_fwd(x, y, res, scale, shift, act):
                _p(shift), act, x.dt, _stream())
 
 
-def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momentum, eps, vec, zero_table, act):
+def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momentum, eps, vec, zero_table, act, stats_ld=0, stats_c0=0):
     """cy_bn_finalize + cy_bn_act_fwd in one launch; vec: float32 [4, C] (mean, invstd, scale, shift) written by the kernel;
     zero_table: the OTHER statistics table of the alternating pair (zeroed by this launch)."""
     lib().call('cy_bn_act_fwd_fused', _p(x), x.ld, _p(y), y.ld, _p(res), res.ld if res is not None else 0, x.M, x.C, _p(bins), rows,
                _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), float(momentum), float(eps), _p(vec), _p(zero_table),
-               zero_table.numel() if zero_table is not None else 0, act, x.dt, _stream())
+               zero_table.numel() if zero_table is not None else 0, act, x.dt, int(stats_ld), int(stats_c0), _stream())
 
 
 def bn_act_bwd_apply_fused(x, dy, dx, res_grad, res_accum, mean, invstd, scale, shift, bins, rows, ggamma, gbeta, gscale,

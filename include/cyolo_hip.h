@@ -59,7 +59,8 @@ int cy_pack_weights(const float* w, int Co, int Ci, int ks, int CoPad, int CiPad
  * with all ks*ks taps and a block covers 256 / lanes pairs (second entry = first pair / 32). */
 typedef struct {
     const float* w; void* wf; void* wd;
-    int Co, Ci, ks, CoPad, CiPad, pad_;
+    int Co, Ci, ks, CoPad, CiPad;
+    int wd_ld;      /* 0, or the row stride (elements) of a WIDER dgrad matrix this layer fills a column range of (ks = 1) */
 } cy_pack_desc;
 typedef struct {
     const float* part; float* grad;
@@ -260,11 +261,13 @@ int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const void* res, int
  * mode, whose per-tile tables are too long to fold in every block): every block folds the CY_STAT_BINS-row table of its
  * channel group in its prologue, the first pixel block of a group writes vec_out[4][C] = (mean, invstd, scale, shift) and
  * updates the running statistics, and the launch zeroes zero_table[0:zero_n] -- the OTHER table of an alternating pair
- * (the one this kernel reads is left as it is: it is zeroed by the next layer's launch). */
+ * (the one this kernel reads is left as it is: it is zeroed by the next layer's launch).  stats_ld > 0: the table's rows are
+ * stats_ld channels wide and this layer's C channels start at column stats_c0 (ONE conv launch over two sibling layers --
+ * the CSP stages' 1x1 pairs -- leaves one table for both; each keeps its own parameters and its own pass); 0: stats_ld = C. */
 int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
                         const float* stats_bins, int rows, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* vec_out,
-                        float* zero_table, int zero_n, int act, int dtype, cy_stream_t s);
+                        float* zero_table, int zero_n, int act, int dtype, int stats_ld, int stats_c0, cy_stream_t s);
 /* cy_bn_bwd_finalize + cy_bn_act_bwd_apply in one launch, same scheme: ggamma / gbeta += gscale * sums by the first pixel
  * block of every channel group. */
 int cy_bn_act_bwd_apply_fused(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, void* res_grad, int ldrg,

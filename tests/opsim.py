@@ -64,7 +64,15 @@ def make_pack_table(items, device):
 
 
 def pack_weights_multi(desc, blocks, dt):
-    for w, wf, wd, cop, cip in desc:
+    for item in desc:
+        w, wf, wd, cop, cip = item[:5]
+        if len(item) > 5 and item[5] and wd is not None:      # ks = 1, a column range of a wider dgrad matrix: wd is a strided view
+            Co, Ci = w.shape[:2]
+            full = torch.zeros(cop, cip)
+            full[:Co, :Ci] = w.detach().reshape(Co, Ci)
+            wf.copy_(full.to(wf.dtype))
+            wd.copy_(full.t().to(wd.dtype))
+            continue
         pack_weights_into(w, cop, cip, dt, wf, wd)
 
 
@@ -134,7 +142,8 @@ def conv_wgrad(dy, x, ks, stride, pad, part, split, use_tr=1):
 
 def wgrad_reduce(part, split, co_rows, ci_pad, ks, Co, Ci, scale, accumulate, grad):
     ncols = ks * ks * ci_pad
-    p = part.view(-1)[:split * co_rows * ncols].view(split, co_rows, ks * ks, ci_pad).sum(0)
+    # (rows [0, Co) of every slab; the slab stride is co_rows * ncols -- `part` may start inside a wider slab and end with it)
+    p = torch.as_strided(part.view(-1), (split, Co, ks * ks, ci_pad), (co_rows * ncols, ncols, ci_pad, 1)).sum(0)
     g = p[:Co, :, :Ci].permute(0, 2, 1).reshape(Co, Ci, ks, ks) * scale
     grad.copy_(grad + g if accumulate else g)
 
@@ -169,9 +178,10 @@ def bn_act_fwd(x, y, res, scale, shift, act):
     _store(y, a)
 
 
-def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momentum, eps, vec, zero_table, act):
+def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momentum, eps, vec, zero_table, act, stats_ld=0, stats_c0=0):
     C = x.C
-    st = bins.view(-1)[:rows * 2 * C].clone()
+    ld = stats_ld or C
+    st = bins.view(-1)[:rows * 2 * ld].view(rows, 2, ld)[:, :, stats_c0:stats_c0 + C].reshape(-1).clone()
     bn_finalize(st, rows, C, x.M, gamma, beta, rmean, rvar, nbt, momentum, eps, vec[0], vec[1], vec[2], vec[3])
     if zero_table is not None:
         zero_table.zero_()

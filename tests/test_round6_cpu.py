@@ -70,3 +70,38 @@ def test_superseded_engine_tables_are_bounded(monkeypatch):
                 p.data = p.data.clone()
         m(x, tg)[0].backward()
     assert len(eng._retired_ws) > n0
+
+
+def test_sibling_convs_fused_equal_the_unfused_plan(monkeypatch):
+    """The two 1x1 convs over one input of every CSP stage (complex_yolov4.cfg:44-64 and the same pattern in the four later
+    stages) as ONE forward conv (joint pre-BN buffer and statistics table), ONE weight gradient and ONE input gradient: the
+    engine with CY_SIBLING_FUSE=2 against the same engine with the pairs switched off, on the CPU operator simulator (fp32):
+    five pairs found, same loss, outputs, running statistics and gradients up to float32 summation order."""
+    import os
+    cfg = os.path.join(os.path.dirname(__file__), '..', 'complex-yolov4-pytorch_amd', 'config', 'cfg', 'complex_yolov4.cfg')
+    opsim.install(monkeypatch)
+    x, tg = syn.bev_images(2, 96, seed=7, sparsity=0.5), syn.targets(2, 4, 96, seed=7)
+    res = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('CY_SIBLING_FUSE', mode)
+        torch.manual_seed(0)
+        m = Darknet(cfg, use_giou_loss=True, dtype='f32')
+        sd = m.state_dict()
+        sd.update({k: syn.fill_tensor(k, tuple(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point})
+        m.load_state_dict(sd)
+        m.train()
+        loss, out = m(x, tg)
+        loss.backward()
+        eng = next(iter(m._engines.values()))
+        res[mode] = (float(loss), out.clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                     {k: v.clone() for k, v in m.state_dict().items() if 'running' in k or 'tracked' in k}, len(eng._sib))
+    assert res['0'][4] == 0 and res['2'][4] == 5
+    assert abs(res['0'][0] - res['2'][0]) <= 1e-5 * abs(res['0'][0])
+    torch.testing.assert_close(res['2'][1], res['0'][1], rtol=1e-4, atol=1e-5)
+    for k, v in res['0'][3].items():
+        torch.testing.assert_close(res['2'][3][k], v, rtol=1e-5, atol=1e-6)
+    worst = 0.0
+    for k, g0 in res['0'][2].items():
+        g2 = res['2'][2][k]
+        worst = max(worst, float((g2 - g0).norm() / (g0.norm() + 1e-12)))
+    assert worst < 1e-3, worst
