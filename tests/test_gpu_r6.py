@@ -427,3 +427,57 @@ def test_sibling_convs_fused_equal_the_unfused_plan_on_device(monkeypatch, dtype
         n0 = torch.stack([g.norm() for g in res['0'][2].values()])
         n2 = torch.stack([g.norm() for g in res['2'][2].values()])
         assert 0.8 < float((n2 / (n0 + 1e-12)).median()) < 1.25
+
+
+@pytest.mark.parametrize('dt', [CY_F16, CY_BF16])
+@pytest.mark.parametrize('case', [(2, 64, 128, 40, 24, 'mish', 0), (3, 64, 64, 37, 21, 'leaky', 8), (1, 64, 128, 1, 5, 'linear', 0),
+                                  (4, 64, 128, 152, 152, 'mish', 16), (2, 128, 128, 8, 8, 'mish', 0)])
+def test_consumer_side_batchnorm_conv(dt, case):
+    """cy_conv1x1_bn_in (the 1x1 conv reads the producer's PRE-BatchNorm rows, applies scale / shift + activation on their way into
+    LDS and writes the activated rows as a side output) = cy_bn_act_fwd followed by cy_conv_igemm on that output: the activated
+    tensor bit for bit (the same float32 expression rounded once), and therefore the conv output and its BatchNorm statistics
+    exactly as the two-launch path's streaming kernel produces them from it.  Ragged pixel counts (M not a multiple of the 128-pixel
+    tile), padded row strides, and a shape outside the instantiated ones (CY_ERR_UNSUPPORTED, nothing written)."""
+    N, Ci, Co, H, W, act, padld = case
+    g = torch.Generator().manual_seed(N * 31 + Co + H)
+    tdt = ops.torch_dtype(dt)
+    raw = View.alloc(N, H, W, Ci, dt, ld=Ci + padld); raw.buf.copy_(torch.randn(raw.buf.numel(), generator=g).to(tdt))
+    a1 = View.alloc(N, H, W, Ci, dt, ld=Ci + padld); a2 = View.alloc(N, H, W, Ci, dt, ld=Ci + padld)
+    o1 = View.alloc(N, H, W, Co, dt, ld=Co + padld); o2 = View.alloc(N, H, W, Co, dt, ld=Co + padld)
+    for v in (a1, a2, o1, o2):
+        v.buf.fill_(7.0)
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) * 0.1).cuda()
+    wf, _ = ops.pack_weights(w, Co, Ci, dt)
+    scale = (torch.rand(Ci, generator=g) + 0.5).cuda()
+    shift = (torch.randn(Ci, generator=g) * 0.3).cuda()
+    rows = ops.conv_stats_rows(raw.M, Co)
+    st1 = torch.zeros((rows + ops.bn_scratch_rows()) * 2 * Co, device='cuda'); st2 = torch.zeros_like(st1)
+    A = ops.ACT[act]
+    if Ci != 64:
+        with pytest.raises(ops.CyoloError) as e:
+            ops.conv1x1_bn_in(raw, scale, shift, A, a2, wf, Co, o2, flags=ops.CONV_STATS, stats=st2)
+        assert 'status -3' in str(e.value)                  # CY_ERR_UNSUPPORTED
+        torch.cuda.synchronize()
+        assert float(a2.buf.float().min()) == 7.0 and float(o2.buf.float().min()) == 7.0 and float(st2.abs().max()) == 0.0
+        return
+    ops.bn_act_fwd(raw, a1, None, scale, shift, A)
+    ops.conv_igemm(a1, wf, Co, o1, 1, 1, 0, flags=ops.CONV_STATS, stats=st1, tile=10)     # (hint 10: the same streaming kernel)
+    ops.conv1x1_bn_in(raw, scale, shift, A, a2, wf, Co, o2, flags=ops.CONV_STATS, stats=st2)
+    torch.cuda.synchronize()
+    # leaky / linear: the same float32 expression rounded once -> bit for bit.  Mish: the two kernels' compilers contract the
+    # exp / reciprocal chain differently -> within one storage ulp, and the conv outputs within what 64 such inputs can move them
+    ulp = 2.0 ** -10 if dt == CY_F16 else 2.0 ** -7
+    if act != 'mish':
+        assert torch.equal(a1.buf, a2.buf)                  # padding columns included: both left at the fill value
+        assert torch.equal(o1.buf, o2.buf)
+    else:
+        da = (a1.buf.float() - a2.buf.float()).abs()
+        assert float((da / a1.buf.float().abs().clamp_min(2.0 ** -6)).max()) <= 1.01 * ulp
+        assert float((da > 0).float().mean()) < 0.02        # and rarely: the roundings agree on > 98 % of the elements
+        do = (o1.buf.float() - o2.buf.float()).abs()
+        assert float(do.max()) <= 4 * ulp * float(o1.buf.float().abs().max())
+    # the statistics are float32 atomics into 16 shared bins: the same addends, bin by block index; their order is not fixed
+    s1 = st1[:rows * 2 * Co].view(rows, 2, Co).sum(0); s2 = st2[:rows * 2 * Co].view(rows, 2, Co).sum(0)
+    assert torch.allclose(s1, s2, rtol=1e-3 if act == 'mish' else 1e-5, atol=(1e-3 if act == 'mish' else 1e-5) * float(s1.abs().max()))
+    ref = (o1.buf.float().view(-1, Co + padld)[:, :Co]).sum(0)
+    assert torch.allclose(s1[0], ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
