@@ -158,7 +158,8 @@ struct BnFoldParams {
     float* rvar;
     long long* nbt;
     float momentum, eps;
-    float* vec;              // [4][C]: mean, invstd, scale, shift
+    float* vec;              // [4][vec_ld]: mean, invstd, scale, shift (vec_ld = C, or the width of a table two layers share)
+    int vec_ld;
 };
 
 __device__ __forceinline__ void zero_other_table(float* t, int n) {
@@ -192,9 +193,9 @@ __global__ void __launch_bounds__(256) bn_act_fwd_fused_kernel(const T* __restri
         s_sh[threadIdx.x] = sh;
         if (blockIdx.x == 0) {
             f.vec[c] = (float)m;
-            f.vec[C + c] = is;
-            f.vec[2 * C + c] = sc;
-            f.vec[3 * C + c] = sh;
+            f.vec[f.vec_ld + c] = is;
+            f.vec[2 * f.vec_ld + c] = sc;
+            f.vec[3 * f.vec_ld + c] = sh;
             if (f.rmean) {
                 const double unb = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
                 f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * (float)m;
@@ -232,7 +233,9 @@ __global__ void __launch_bounds__(256) bn_act_fwd_fused_kernel(const T* __restri
 }
 
 struct BnBwdFoldParams {
-    const float* bins;       // [CY_STAT_BINS][2][C]: sum dz, sum dz * xhat
+    const float* bins;       // [CY_STAT_BINS][2][bins_ld]: sum dz, sum dz * xhat; this layer's channels from column bins_c0 (one dgrad
+                             // launch that last writes the output gradients of TWO layers -- a CSP concatenation -- leaves one table)
+    int bins_ld, bins_c0;
     float* zero_table;
     int zero_n;
     float* ggamma;
@@ -255,8 +258,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_fused_kernel(const T* __rest
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int b = 0; b < CY_STAT_BINS; ++b) {
-            s1 += (double)f.bins[((size_t)b * 2) * C + c];
-            s2 += (double)f.bins[((size_t)b * 2 + 1) * C + c];
+            s1 += (double)f.bins[((size_t)b * 2) * f.bins_ld + f.bins_c0 + c];
+            s2 += (double)f.bins[((size_t)b * 2 + 1) * f.bins_ld + f.bins_c0 + c];
         }
         s_db[threadIdx.x] = (float)s1;
         s_dg[threadIdx.x] = (float)s2;
@@ -1002,9 +1005,10 @@ extern "C" int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, con
                                    const float* stats_bins, int rows, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                    float eps, float* vec_out, float* zero_table, int zero_n, int act, int dtype,
-                                   int stats_ld, int stats_c0, cy_stream_t s) {
+                                   int stats_ld, int stats_c0, int vec_ld, cy_stream_t s) {
     CY_ENTER();
     const int ch = dtype == CY_F32 ? 4 : 8;
+    if (vec_ld != 0 && vec_ld < C) return CY_ERR_ARG;
     if (!x || !y || !stats_bins || !gamma || !beta || !vec_out || rows != CY_BINS || M < 1 || C % ch || ldx % ch || ldy % ch ||
         (res && ldres % ch) || (zero_n > 0 && !zero_table) || zero_table == stats_bins)
         return CY_ERR_ARG;
@@ -1018,7 +1022,7 @@ extern "C" int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, con
     BnFoldParams f;
     f.bins = stats_bins; f.zero_table = zero_table; f.zero_n = zero_n; f.count = (double)M; f.gamma = gamma; f.beta = beta;
     f.rmean = running_mean; f.rvar = running_var; f.nbt = (long long*)num_batches_tracked; f.momentum = momentum; f.eps = eps;
-    f.vec = vec_out;
+    f.vec = vec_out; f.vec_ld = vec_ld > 0 ? vec_ld : C;
     f.bins_ld = stats_ld > 0 ? stats_ld : C; f.bins_c0 = stats_ld > 0 ? stats_c0 : 0;
     if (f.bins_c0 < 0 || f.bins_c0 + C > f.bins_ld) return CY_ERR_ARG;
 #define CY_BNFF(T, A)                                                                                                  \
@@ -1041,7 +1045,7 @@ extern "C" int cy_bn_act_bwd_apply_fused(const void* x, int ldx, const void* dy,
                                          int ldrg, int res_accum, int64_t M, int C, const float* mean, const float* invstd,
                                          const float* scale, const float* shift, const float* part_bins, int rows,
                                          float* ggamma, float* gbeta, float gscale, float* zero_table, int zero_n, int act,
-                                         int dtype, cy_stream_t s) {
+                                         int dtype, int bins_ld, int bins_c0, cy_stream_t s) {
     CY_ENTER();
     const int ch = dtype == CY_F32 ? 4 : 8;
     if (!x || !dy || !dx || !part_bins || !mean || !invstd || !scale || !shift || rows != CY_BINS || M < 1 || C % ch || ldx % ch ||
@@ -1056,6 +1060,8 @@ extern "C" int cy_bn_act_bwd_apply_fused(const void* x, int ldx, const void* dy,
     const dim3 grid((unsigned)((M + ppb - 1) / ppb), (unsigned)(C / cg));
     BnBwdFoldParams f;
     f.bins = part_bins; f.zero_table = zero_table; f.zero_n = zero_n; f.ggamma = ggamma; f.gbeta = gbeta; f.gscale = gscale;
+    f.bins_ld = bins_ld > 0 ? bins_ld : C; f.bins_c0 = bins_ld > 0 ? bins_c0 : 0;
+    if (f.bins_c0 < 0 || f.bins_c0 + C > f.bins_ld) return CY_ERR_ARG;
 #define CY_BNAF(T, A)                                                                                                 \
     hipLaunchKernelGGL((bn_bwd_apply_fused_kernel<T, A>), grid, dim3(256), 0, cy_s(s), (const T*)x, ldx, (const T*)dy, lddy, \
                        (T*)dx, lddx, (T*)res_grad, ldrg, res_accum, (long)M, C, cg, mean, invstd, scale, shift, f, (int)ppb);

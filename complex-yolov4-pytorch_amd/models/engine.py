@@ -114,7 +114,18 @@ class Engine:
         if (training and (dt != CY_F32 or sf == '2') and not deterministic and hasattr(ops, 'bn_act_fwd_fused')
                 and os.environ.get('CY_FUSED_BN', '1') != '0' and sf != '0'):
             self._find_siblings(plan)
+        # BatchNorm-backward sums of the TWO producers of a CSP concatenation in the epilogue of the closing conv's dgrad (round 6;
+        # graph.py 'dx_sums_cat'): conv idx of that closing conv P -> record; member layer idx -> (record, first column of its
+        # channels in the record's tables).  CY_CAT_SUMS: 0 off, 1 (default) timed per stage against dgrad + two reduce passes,
+        # 2 untimed (the CPU simulator's tests).  See _find_cats.
+        self._cat, self._cat_of, self._cat_on = {}, {}, {}
+        self.cat_sums = int(os.environ.get('CY_CAT_SUMS', '1'))
+        if (training and self.cat_sums and self.dgrad_bn_sums and not deterministic and hasattr(ops, 'bn_act_fwd_fused')
+                and hasattr(ops, 'conv_dgrad_bn_sums') and os.environ.get('CY_FUSED_BN', '1') != '0'
+                and (dt != CY_F32 or getattr(device, 'type', str(device)) != 'cuda')):
+            self._find_cats(plan)
         sib_raw = {r['raw'].st.sid for pr in self._sib.values() for r in (pr['a'], pr['b'])}
+        sib_raw |= {L['raw'].st.sid for ct in self._cat.values() for L in (ct['L1'], ct['L2'])}
         max_raw = 0
         for st in plan.storages:
             n = N * st.H * st.W * st.C
@@ -131,10 +142,30 @@ class Engine:
                 if training and st.kind == 'act':
                     self.gact[st.sid] = new('gact %r' % (st,), n, self.tdt)
         self.raw_scratch = new('raw_scratch', max(max_raw, 1), self.tdt)
+        for ct in self._cat.values():
+            # the pre-BN tensors of the concatenation's two producers side by side: [L1 | L2], or [L1 | A | B] when L2 is the lead A of
+            # a sibling pair (whose joint conv then writes columns C1 ... of a 3-wide buffer).  Each layer's own view has the joint
+            # row stride; the closing conv's dgrad epilogue reads columns 0 ... C1 + C2 as ONE pre-BN tensor
+            L1, L2, C1, C2 = ct['L1'], ct['L2'], ct['C1'], ct['C2']
+            pr = self._sib.get(L2['idx'])
+            wide = C1 + C2 + (pr['Cb'] if pr is not None else 0)
+            H, W = L1['H'], L1['W']
+            buf = new('raw concat %d+%d' % (L1['idx'], L2['idx']), N * H * W * wide, self.tdt)
+            ct['raw'] = View(buf, 0, N, H, W, C1 + C2, wide, dt)
+            members = [(L1, 0, C1), (L2, C1, C2)]
+            if pr is not None:
+                members.append((pr['b'], C1 + C2, pr['Cb']))
+                pr['raw'] = (View(buf, C1, N, H, W, C2, wide, dt), View(buf, C1 + C2, N, H, W, pr['Cb'], wide, dt),
+                             View(buf, C1, N, H, W, C2 + pr['Cb'], wide, dt))
+            for r, c0, C in members:
+                self._views[(id(r['raw']), False)] = View(buf, c0, N, H, W, C, wide, dt)
+                self._view_refs.append(r['raw'])
         for lead, pr in self._sib.items():
             A, B, Ca, Cb = pr['a'], pr['b'], pr['Ca'], pr['Cb']
             CJ, H, W = Ca + Cb, A['H'], A['W']
             for nm in ('raw', 'draw'):      # [A | B]: the conv's output / the two BatchNorm backwards' output (dY of the fused wgrad / dgrad)
+                if nm in pr:
+                    continue                # (the pre-BN buffer is part of a concatenation's, above)
                 buf = new('%s siblings %d+%d' % (nm, A['idx'], B['idx']), N * H * W * CJ, self.tdt)
                 pr[nm] = (View(buf, 0, N, H, W, Ca, CJ, dt), View(buf, Ca, N, H, W, Cb, CJ, dt), View(buf, 0, N, H, W, CJ, CJ, dt))
             for r, v in ((A, pr['raw'][0]), (B, pr['raw'][1])):
@@ -145,6 +176,12 @@ class Engine:
             pr['rec'].pop('_names', None)
         # per-conv persistent BN vectors and packed weights; shared scratch for the reductions
         self.bnvec, self.wf, self.wd = {}, {}, {}
+        for ct in self._cat.values():
+            # (mean, invstd, scale, shift) of the two producers as ONE [4][C1 + C2] block: each layer's own vectors are column
+            # ranges of it (cy_bn_act_fwd_fused writes them with vec_ld = C1 + C2)
+            ct['vec'] = new('bnvec concat %d+%d' % (ct['L1']['idx'], ct['L2']['idx']), (4, ct['C1'] + ct['C2']), torch.float32)
+            self.bnvec[ct['L1']['idx']] = ct['vec'][:, :ct['C1']]
+            self.bnvec[ct['L2']['idx']] = ct['vec'][:, ct['C1']:]
         max_stats = max_bnrows = max_c = 1
         max_wpart = 0
         self.wsplit, self.wslab_off, self.wsplit_cap = {}, {}, {}
@@ -169,7 +206,8 @@ class Engine:
                 self.wf[rec['idx']] = new('wf[%d]' % rec['idx'], (cop, kk * cip), self.tdt)
                 self.wd[rec['idx']] = new('wd[%d]' % rec['idx'], (cip, kk * cop), self.tdt) if training and not rec['first'] else None
             if rec['bn']:
-                self.bnvec[rec['idx']] = new('bnvec[%d]' % rec['idx'], (4, C), torch.float32)
+                if rec['idx'] not in self.bnvec:
+                    self.bnvec[rec['idx']] = new('bnvec[%d]' % rec['idx'], (4, C), torch.float32)
                 max_stats = max(max_stats, ops.conv_stats_rows(M, C, self.det) * 2 * C)
                 max_c = max(max_c, C)
                 if training:
@@ -192,7 +230,17 @@ class Engine:
         # (the first statistics table and both BN-backward tables share one allocation: a training step zeroes them with ONE
         # fill at the top of the forward pass -- nothing touches the backward tables before the backward pass)
         _r64 = lambda n: (n + 63) // 64 * 64
-        self._ztab = new('ztab (stats + bn-backward tables)', _r64(max_stats) + 2 * _r64(max_bnrows), torch.float32, zero=True)
+        cat_floats = sum(_r64(ops.conv_stats_rows(N * ct['L1']['H'] * ct['L1']['W'], ct['C1'] + ct['C2']) * 2 * (ct['C1'] + ct['C2']))
+                         for ct in self._cat.values())
+        self._ztab = new('ztab (stats + bn-backward tables)', _r64(max_stats) + 2 * _r64(max_bnrows) + cat_floats, torch.float32, zero=True)
+        # (the concatenation sums tables live behind them: filled by the closing conv's dgrad, read by two BatchNorm backward passes
+        # that may run much later -- not part of the alternating pair; zeroed with everything else at the top of the forward pass)
+        off = _r64(max_stats) + 2 * _r64(max_bnrows)
+        self._cat_tables = self._ztab[off:]
+        for ct in self._cat.values():
+            n = ops.conv_stats_rows(N * ct['L1']['H'] * ct['L1']['W'], ct['C1'] + ct['C2']) * 2 * (ct['C1'] + ct['C2'])
+            ct['tbl'] = self._ztab[off:off + n]
+            off += _r64(n)
         self.stats = self._ztab[:max_stats]
         self.bnpart = self._ztab[_r64(max_stats):_r64(max_stats) + max_bnrows]
         # default (non-deterministic) mode: the fold runs in the prologue of the consuming kernel (cy_bn_act_fwd_fused /
@@ -333,6 +381,24 @@ class Engine:
                 continue
             self._sib[A['idx']] = dict(a=A, b=B, Ca=A['cout'], Cb=B['cout'])
             self._sib_follow[B['idx']] = A['idx']
+
+    def _find_cats(self, plan):
+        """The closing 1x1 conv P of a CSP stage reads [L1 | L2] (the B path's last conv and the sibling A: route layers=-1,-7) and its
+        input gradient is the last writer of both layers' output gradients -- the plan marks such runs as 'dx_sums_cat'.  Taken here
+        when neither layer is the FOLLOWER of a sibling pair and L1 is in no pair (the joint pre-BN buffer is then [L1 | L2] or
+        [L1 | A | B])."""
+        for b in plan.bwd:
+            for ri, (L1, L2) in b.get('dx_sums_cat', {}).items():
+                P = b['fwd']
+                if (P['idx'] in self._sib_follow or P['idx'] in self._sib or L1['idx'] in self._sib or L1['idx'] in self._sib_follow
+                        or L2['idx'] in self._sib_follow or P['idx'] in self._cat or ri != 0 or len(b['dx']) != 1):
+                    continue
+                if L1['idx'] in self._cat_of or L2['idx'] in self._cat_of or L1['cout'] % 32 or L2['cout'] % 32:
+                    continue
+                ct = dict(P=P, L1=L1, L2=L2, C1=L1['cout'], C2=L2['cout'], act=L1['act'])
+                self._cat[P['idx']] = ct
+                self._cat_of[L1['idx']] = (ct, 0)
+                self._cat_of[L2['idx']] = (ct, L1['cout'])
 
     def _pair(self, idx):
         """-> (pair record, 0 for the lead | 1 for the follower) or (None, None)."""
@@ -613,6 +679,7 @@ class Engine:
         mean, invstd, scale, shift = vec[0], vec[1], vec[2], vec[3]
         C, M = rec['cout'], raw.M
         pr, role = self._pair(idx)
+        vld = vec.stride(0) if idx in self._cat_of else 0      # (its vectors are columns of a concatenation's [4][C1 + C2] block)
         if pr is not None:
             # sibling pair: the lead's launch convolves with the joint matrix and leaves ONE statistics table of Ca + Cb channels;
             # each module's BatchNorm + activation pass reads its slice of it (and of the joint pre-BN buffer).  The tables
@@ -628,12 +695,12 @@ class Engine:
             ops.bn_act_fwd_fused(raw, self.view(rec['out']), res, tbl, ops.conv_stats_rows(M, CJ), P[bname + '.weight'],
                                  P[bname + '.bias'], P[bname + '.running_mean'], P[bname + '.running_var'],
                                  P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, vec, other, ops.ACT[rec['act']],
-                                 stats_ld=CJ, stats_c0=0 if role == 0 else pr['Ca'])
+                                 stats_ld=CJ, stats_c0=0 if role == 0 else pr['Ca'], vec_ld=vld)
             return
         if self.training and self.fused_bn:
             tbl, other = self.stats_pair[self._sp], self.stats_pair[self._sp ^ 1]
             self._sp ^= 1
-            fh = self._fwd_fused.get(idx)
+            fh = self._fwd_fused.get(idx) if not vld else None
             if fh is not None:
                 res = self.view(rec['res']) if rec['res'] is not None else None
                 with ops.prof('igemm', *self._conv_work(rec)):
@@ -648,7 +715,7 @@ class Engine:
             res = self.view(rec['res']) if rec['res'] is not None else None
             ops.bn_act_fwd_fused(raw, self.view(rec['out']), res, tbl, ops.conv_stats_rows(M, C), P[bname + '.weight'],
                                  P[bname + '.bias'], P[bname + '.running_mean'], P[bname + '.running_var'],
-                                 P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, vec, other, ops.ACT[rec['act']])
+                                 P.get(bname + '.num_batches_tracked'), BN_MOMENTUM, BN_EPS, vec, other, ops.ACT[rec['act']], vec_ld=vld)
             return
         if self.training:
             with ops.prof('igemm', *self._conv_work(rec)):
@@ -799,6 +866,8 @@ class Engine:
             if self._bn_tables_fwd != self.fwd_serial:     # (zeroed by this step's forward pass otherwise)
                 self.bnpart_pair[0].zero_()
                 self.bnpart_pair[1].zero_()
+                if self._cat:
+                    self._cat_tables.zero_()
             self._bn_tables_fwd = -1
         key = prog = None
         can = (self.replay and tuned and on_dev and self._fwd_key is not None and ops.PROFILER is None and ops.recording() is None)
@@ -1115,6 +1184,9 @@ class Engine:
                     if sim or (self.dt != CY_F32 and b['fwd']['cout'] % 64 == 0 and L['cout'] % 8 == 0):   # what the kernel takes
                         self._dgrad_sums[(b['fwd']['idx'], b['dx'][ri][0].c0)] = (L, 6)
                         self._sums_fused.add(L['idx'])
+                ct = self._cat.get(b['fwd']['idx']) if b['op'] == 'conv_bwd' else None
+                if ct is not None and (sim or b['fwd']['cout'] % 64 == 0):
+                    self._take_cat(b, ct, 6)
             return
         if not self._tunable():
             return
@@ -1146,17 +1218,36 @@ class Engine:
                     ks=(1 if rec['ks'] == 1 and rec['stride'] == 1 else 0), extra=s2, slab=_slab_shape(rec))
                 self._dgrad_tile[(rec['idx'], ref.c0)] = hint
                 L = b.get('dx_sums', {}).get(ri) if can_fuse else None
-                if L is None:
+                ct = self._cat.get(rec['idx']) if (can_fuse and L is None and pr is None and ri == 0 and id(rec) not in heads) else None
+                if L is None and ct is None:
                     continue
                 # fused (dgrad + sums in its epilogue) against separate (best dgrad, then the reduce pass over raw and gradient)
-                vec, raw, act = self.bnvec[L['idx']], self.view(L['raw']), ops.ACT[L['act']]
-                tbl = self.bnpart_pair[0]
+                if ct is not None:      # the two producers of a concatenation as ONE 'layer' of C1 + C2 channels
+                    vec, raw, act, tbl = ct['vec'], ct['raw'], ops.ACT[ct['act']], ct['tbl']
+                else:
+                    vec, raw, act = self.bnvec[L['idx']], self.view(L['raw']), ops.ACT[L['act']]
+                    tbl = self.bnpart_pair[0]
                 fhint, t_fused = self._time_hints_t(('dgrad+sums', act, raw.ld) + key[1:], lambda h: ops.conv_dgrad_bn_sums(
                     dy, wd[r0:r0 + ref.C], ref.C, gv, rec['ks'], rec['stride'], rec['pad'], raw, vec[0], vec[1], vec[2], vec[3],
                     act, tbl, flags=flags, tile=h), dy.C, ref.C, pipe_only=True,
                     extra=s2 or ((10,) if (rec['ks'] == 1 and rec['stride'] == 1 and (dy.C, ref.C) in _PW_DIRECT) else ()),
                     slab=_slab_shape(rec))
                 if fhint is None:
+                    continue
+                if ct is not None:
+                    t_reduce = 0.0
+                    for Lp in (ct['L1'], ct['L2']):      # what the stage pays now: one reduce pass per producer
+                        rv, gp, vp = self.view(Lp['raw']), self.view(Lp['out'], grad=True), self.bnvec[Lp['idx']]
+                        rows = ops.bn_bwd_rows(rv.M, rv.C, self.dt, False)
+                        _, t = self._time_hints_t(('bn_bwd_reduce', act, self.dt, rv.M, rv.C, rv.ld, gp.ld), lambda h: ops.bn_act_bwd_reduce(
+                            rv, gp, vp[0], vp[1], vp[2], vp[3], act, self.bnpart_pair[0], rows), 0, 0, hints=[1])
+                        t_reduce += t
+                    if os.environ.get('CY_TUNE_VERBOSE'):
+                        print('dgrad+sums L%d|L%d <- conv %d (k%d %d->%d @%d): plain hint %s %.1f us + 2 reduces %.1f us vs fused hint %s %.1f us'
+                              % (ct['L1']['idx'], ct['L2']['idx'], rec['idx'], rec['ks'], dy.C, ref.C, gv.H, hint, 1e3 * t_plain,
+                                 1e3 * t_reduce, fhint, 1e3 * t_fused), flush=True)
+                    if self.cat_sums == 2 or t_fused < t_plain + t_reduce:
+                        self._take_cat(b, ct, fhint)
                     continue
                 rows = ops.bn_bwd_rows(raw.M, raw.C, self.dt, False)
                 _, t_reduce = self._time_hints_t(('bn_bwd_reduce', act, self.dt, raw.M, raw.C, raw.ld, gv.ld), lambda h: ops.bn_act_bwd_reduce(
@@ -1171,6 +1262,16 @@ class Engine:
         if self.bnpart_pair is not None:     # the timed launches added into the sum tables
             self.bnpart_pair[0].zero_()
             self.bnpart_pair[1].zero_()
+            if self._cat:
+                self._cat_tables.zero_()
+
+    def _take_cat(self, b, ct, hint):
+        """The closing conv's dgrad takes the BatchNorm-backward sums of both producers of its concatenation (hint = its tile)."""
+        rec = b['fwd']
+        self._dgrad_sums[(rec['idx'], b['dx'][0][0].c0)] = (dict(idx=None, act=ct['act'], cat=ct), hint)
+        for L, c0 in ((ct['L1'], 0), (ct['L2'], ct['C1'])):
+            self._sums_fused.add(L['idx'])
+            self._cat_on[L['idx']] = (ct, c0)
 
     def _wgrad(self, rec, dy, xv):
         """Weight gradient of one conv.  It is off the critical path of backward (only the optimizer needs it), so it
@@ -1247,13 +1348,15 @@ class Engine:
             with ops.prof('igemm_sums' if fused is not None else 'igemm', fl * ref.C / x.C,
                           by + (self.view(ref, grad=True).M * ref.C * 2 if fused is not None else 0)):
                 if fused is not None:
-                    # the sums of layer L go into the table L's backward will pick next (zeroed by the apply pass that just ran)
+                    # the sums of layer L go into the table L's backward will pick next (zeroed by the apply pass that just ran);
+                    # those of a concatenation's two producers into that concatenation's own table
                     L, hint = fused
-                    vec = self.bnvec[L['idx']]
+                    ct = L.get('cat')
+                    vec = self.bnvec[L['idx']] if ct is None else ct['vec']
                     ops.conv_dgrad_bn_sums(dy, wd[r0:r0 + ref.C], ref.C, self.view(ref, grad=True), rec['ks'], rec['stride'],
-                                           rec['pad'], self.view(L['raw']), vec[0], vec[1], vec[2], vec[3], ops.ACT[L['act']],
-                                           self.bnpart_pair[self._bp], flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0),
-                                           tile=hint)
+                                           rec['pad'], self.view(L['raw']) if ct is None else ct['raw'], vec[0], vec[1], vec[2], vec[3],
+                                           ops.ACT[L['act']], self.bnpart_pair[self._bp] if ct is None else ct['tbl'],
+                                           flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0), tile=hint)
                     continue
                 ops.conv_igemm(dy, wd[r0:r0 + ref.C], ref.C, self.view(ref, grad=True), rec['ks'], rec['stride'],
                                rec['pad'], flags=CONV_TRANSPOSED | (CONV_ACCUM if acc else 0),
@@ -1269,11 +1372,15 @@ class Engine:
         C, M = rec['cout'], raw.M
         act = ops.ACT[rec['act']]
         rows = ops.bn_bwd_rows(M, C, self.dt, self.det)
+        bld = bc0 = 0
         if self.fused_bn:
             tbl, other = self.bnpart_pair[self._bp], self.bnpart_pair[self._bp ^ 1]
             self._bp ^= 1
             if idx in self._sums_fused:      # the dgrad that last wrote g already left the sums in tbl
                 rows = ops.conv_stats_rows(M, C, False)
+                if idx in self._cat_on:      # ... in its concatenation's table (this layer's columns); the pair alternates as ever
+                    ct, bc0 = self._cat_on[idx]
+                    tbl, bld = ct['tbl'], ct['C1'] + ct['C2']
             else:
                 ops.bn_act_bwd_reduce(raw, g, mean, invstd, scale, shift, act, tbl, rows)
         else:
@@ -1297,7 +1404,8 @@ class Engine:
             # dRaw into its slice of the joint buffer instead of in place; after A's, ONE weight gradient (dY = [A | B]) and ONE
             # input gradient (K = Ca + Cb, a store: no fan-in read-add-store) run on the joint operands
             ops.bn_act_bwd_apply_fused(raw, g, pr['draw'][role], res_view, res_acc, mean, invstd, scale, shift, tbl, rows,
-                                       self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls, other, act)
+                                       self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls, other, act,
+                                       bins_ld=bld, bins_c0=bc0)
             if role == 0:
                 self._wgrad(pr['rec'], pr['draw'][2], self.view(rec['x']))
                 self._dgrad(pr['rec'], pr['draw'][2], [(b['dx'][0][0], False)])
@@ -1310,7 +1418,8 @@ class Engine:
             return
         if self.fused_bn:
             ops.bn_act_bwd_apply_fused(raw, g, g, res_view, res_acc, mean, invstd, scale, shift, tbl, rows,
-                                       self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls, other, act)
+                                       self.grads[bname + '.weight'], self.grads[bname + '.bias'], 1.0 / self.ls, other, act,
+                                       bins_ld=bld, bins_c0=bc0)
         else:
             ops.bn_act_bwd_apply(raw, g, g, res_view, res_acc, mean, invstd, scale, shift, self.dgs, self.dbs, act)
         self._wgrad(rec, g, self.view(rec['x']))

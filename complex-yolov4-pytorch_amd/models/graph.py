@@ -380,6 +380,7 @@ class Plan:
         alternating sum tables rely on that).  Marks ``b_P['dx_sums'][run index] = L's record`` and
         ``b_L['sums_from'] = P's index``; the engine decides per layer whether to use it."""
         last = {}            # (storage id, channel) -> (bwd index, kind, run index) of the latest write
+        cat = {}             # (bwd index of P, run index) -> BN conv layers whose whole output gradient that run last writes
         prev_conv = None     # bwd index of the latest conv_bwd / head_conv_bwd
         for bi, b in enumerate(self.bwd):
             op = b['op']
@@ -396,6 +397,13 @@ class Plan:
                     if ref.st is out.st and ref.c0 == out.c0 and ref.C == out.C and L['cout'] % 8 == 0:
                         pb.setdefault('dx_sums', {})[w[2]] = L
                         b['sums_from'] = pb['fwd']['idx']
+                if w is not None and w[1] == 'dgrad' and b['sums_from'] is None:
+                    # L's output is PART of what that dgrad run writes (a [route] concatenation of several layers' outputs, each
+                    # consumed by nothing else): a candidate for sums over the whole run -- see 'dx_sums_cat' below
+                    pb = self.bwd[w[0]]
+                    ref, _ = pb['dx'][w[2]]
+                    if ref.st is out.st and ref.c0 <= out.c0 and out.c0 + out.C <= ref.c0 + ref.C and L['cout'] % 8 == 0:
+                        cat.setdefault((w[0], w[2]), []).append(L)
             if op in ('conv_bwd', 'head_conv_bwd'):
                 prev_conv = bi
             writes = []
@@ -410,3 +418,18 @@ class Plan:
             for ref, kind, ri in writes:
                 for c in range(ref.c0, ref.c0 + ref.C):
                     last[(ref.st.sid, c)] = (bi, kind, ri)
+        # 'dx_sums_cat': a stride-1 dgrad run that is the last writer of the output gradients of exactly TWO BatchNorm conv layers
+        # with the same activation, side by side (the closing 1x1 conv of a CSP stage over [branch | sibling]: complex_yolov4.cfg's
+        # route layers=-1,-7).  The run may take both layers' BatchNorm-backward sums in its epilogue when the engine keeps their
+        # pre-BN tensors and their (mean, invstd, scale, shift) vectors side by side; the sums live in a table of their own, so
+        # the two layers' backward ops need not follow P directly.  b_P['dx_sums_cat'][run] = (first layer, second layer).
+        for (bi, ri), parts in cat.items():
+            pb = self.bwd[bi]
+            ref, _ = pb['dx'][ri]
+            parts = sorted(parts, key=lambda L: L['out'].c0)
+            if (len(parts) == 2 and pb['op'] == 'conv_bwd' and pb['fwd']['stride'] == 1 and parts[0]['out'].c0 == ref.c0
+                    and parts[0]['out'].c0 + parts[0]['out'].C == parts[1]['out'].c0
+                    and parts[1]['out'].c0 + parts[1]['out'].C == ref.c0 + ref.C and parts[0]['act'] == parts[1]['act']
+                    and parts[0]['H'] == parts[1]['H'] and parts[0]['W'] == parts[1]['W']
+                    and parts[0].get('res') is None and parts[1].get('res') is None):
+                pb.setdefault('dx_sums_cat', {})[ri] = (parts[0], parts[1])

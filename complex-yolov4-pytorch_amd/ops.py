@@ -503,21 +503,22 @@ def bn_act_fwd(x, y, res, scale, shift, act):
                _p(shift), act, x.dt, _stream())
 
 
-def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momentum, eps, vec, zero_table, act, stats_ld=0, stats_c0=0):
+def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momentum, eps, vec, zero_table, act, stats_ld=0, stats_c0=0,
+                     vec_ld=0):
     """cy_bn_finalize + cy_bn_act_fwd in one launch; vec: float32 [4, C] (mean, invstd, scale, shift) written by the kernel;
     zero_table: the OTHER statistics table of the alternating pair (zeroed by this launch)."""
     lib().call('cy_bn_act_fwd_fused', _p(x), x.ld, _p(y), y.ld, _p(res), res.ld if res is not None else 0, x.M, x.C, _p(bins), rows,
-               _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), float(momentum), float(eps), _p(vec), _p(zero_table),
-               zero_table.numel() if zero_table is not None else 0, act, x.dt, int(stats_ld), int(stats_c0), _stream())
+               _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), float(momentum), float(eps), _p(vec[0] if vec_ld else vec), _p(zero_table),
+               zero_table.numel() if zero_table is not None else 0, act, x.dt, int(stats_ld), int(stats_c0), int(vec_ld), _stream())
 
 
 def bn_act_bwd_apply_fused(x, dy, dx, res_grad, res_accum, mean, invstd, scale, shift, bins, rows, ggamma, gbeta, gscale,
-                           zero_table, act):
+                           zero_table, act, bins_ld=0, bins_c0=0):
     """cy_bn_bwd_finalize + cy_bn_act_bwd_apply in one launch."""
     lib().call('cy_bn_act_bwd_apply_fused', _p(x), x.ld, _p(dy), dy.ld, _p(dx), dx.ld, _p(res_grad),
                res_grad.ld if res_grad is not None else 0, int(res_accum), x.M, x.C, _p(mean), _p(invstd), _p(scale), _p(shift),
                _p(bins), rows, _p(ggamma), _p(gbeta), float(gscale), _p(zero_table),
-               zero_table.numel() if zero_table is not None else 0, act, x.dt, _stream())
+               zero_table.numel() if zero_table is not None else 0, act, x.dt, int(bins_ld), int(bins_c0), _stream())
 
 
 def fold_rows_out(rows):

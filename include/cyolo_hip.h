@@ -277,17 +277,21 @@ int cy_bn_act_fwd(const void* x, int ldx, void* y, int ldy, const void* res, int
  * updates the running statistics, and the launch zeroes zero_table[0:zero_n] -- the OTHER table of an alternating pair
  * (the one this kernel reads is left as it is: it is zeroed by the next layer's launch).  stats_ld > 0: the table's rows are
  * stats_ld channels wide and this layer's C channels start at column stats_c0 (ONE conv launch over two sibling layers --
- * the CSP stages' 1x1 pairs -- leaves one table for both; each keeps its own parameters and its own pass); 0: stats_ld = C. */
+ * the CSP stages' 1x1 pairs -- leaves one table for both; each keeps its own parameters and its own pass); 0: stats_ld = C.
+ * vec_ld > 0: vec_out's four rows are vec_ld floats apart (two layers whose output gradients ONE dgrad launch writes -- the
+ * producers of a CSP concatenation -- keep their (mean, invstd, scale, shift) side by side in one [4][C1 + C2] block, so that
+ * cy_conv_dgrad_bn_sums can take both layers' BatchNorm-backward sums in that launch); 0: vec_ld = C. */
 int cy_bn_act_fwd_fused(const void* x, int ldx, void* y, int ldy, const void* res, int ldres, int64_t M, int C,
                         const float* stats_bins, int rows, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* vec_out,
-                        float* zero_table, int zero_n, int act, int dtype, int stats_ld, int stats_c0, cy_stream_t s);
+                        float* zero_table, int zero_n, int act, int dtype, int stats_ld, int stats_c0, int vec_ld, cy_stream_t s);
 /* cy_bn_bwd_finalize + cy_bn_act_bwd_apply in one launch, same scheme: ggamma / gbeta += gscale * sums by the first pixel
- * block of every channel group. */
+ * block of every channel group.  bins_ld > 0: the rows of part_bins are bins_ld channels wide and this layer's C channels start at
+ * column bins_c0 (a table cy_conv_dgrad_bn_sums filled for two layers at once, see cy_bn_act_fwd_fused's vec_ld); 0: bins_ld = C. */
 int cy_bn_act_bwd_apply_fused(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, void* res_grad, int ldrg,
                               int res_accum, int64_t M, int C, const float* mean, const float* invstd, const float* scale,
                               const float* shift, const float* part_bins, int rows, float* ggamma, float* gbeta,
-                              float gscale, float* zero_table, int zero_n, int act, int dtype, cy_stream_t s);
+                              float gscale, float* zero_table, int zero_n, int act, int dtype, int bins_ld, int bins_c0, cy_stream_t s);
 /* Backward pass 1: per-channel partial sums of dz and dz*xhat, dz = dy*act'(x*scale+shift), ADDED (fp32 atomics) into
  * part[row][2][C]; zero on entry, cy_bn_bwd_finalize(rows) folds it and leaves it zeroed.  rows = cy_bn_bwd_rows()
  * (64 bins shared by the blocks) or cy_bn_bwd_rows_det() (one row per block: run-to-run deterministic). */

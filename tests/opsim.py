@@ -178,8 +178,10 @@ def bn_act_fwd(x, y, res, scale, shift, act):
     _store(y, a)
 
 
-def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momentum, eps, vec, zero_table, act, stats_ld=0, stats_c0=0):
+def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momentum, eps, vec, zero_table, act, stats_ld=0, stats_c0=0,
+                     vec_ld=0):
     C = x.C
+    assert vec_ld in (0, vec.stride(0)), 'vec_ld names the row stride of the (possibly shared) [4][vec_ld] block'
     ld = stats_ld or C
     st = bins.view(-1)[:rows * 2 * ld].view(rows, 2, ld)[:, :, stats_c0:stats_c0 + C].reshape(-1).clone()
     bn_finalize(st, rows, C, x.M, gamma, beta, rmean, rvar, nbt, momentum, eps, vec[0], vec[1], vec[2], vec[3])
@@ -189,10 +191,11 @@ def bn_act_fwd_fused(x, y, res, bins, rows, gamma, beta, rmean, rvar, nbt, momen
 
 
 def bn_act_bwd_apply_fused(x, dy, dx, res_grad, res_accum, mean, invstd, scale, shift, bins, rows, ggamma, gbeta, gscale,
-                           zero_table, act):
+                           zero_table, act, bins_ld=0, bins_c0=0):
     C = x.C
     dgs, dbs = torch.zeros(C), torch.zeros(C)
-    st = bins.view(-1)[:rows * 2 * C].clone()
+    ld = bins_ld or C
+    st = bins.view(-1)[:rows * 2 * ld].view(rows, 2, ld)[:, :, bins_c0:bins_c0 + C].reshape(-1).clone()
     bn_bwd_finalize(st, rows, C, dgs, dbs, ggamma, gbeta, gscale)
     if zero_table is not None:
         zero_table.zero_()

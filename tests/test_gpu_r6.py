@@ -481,3 +481,136 @@ def test_consumer_side_batchnorm_conv(dt, case):
     assert torch.allclose(s1, s2, rtol=1e-3 if act == 'mish' else 1e-5, atol=(1e-3 if act == 'mish' else 1e-5) * float(s1.abs().max()))
     ref = (o1.buf.float().view(-1, Co + padld)[:, :Co]).sum(0)
     assert torch.allclose(s1[0], ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('dt', [CY_F16, CY_BF16])
+@pytest.mark.parametrize('case', [(2, 64, 64, 64, 40, 24, 'mish'), (1, 128, 128, 128, 19, 19, 'leaky'), (3, 32, 64, 0, 33, 17, 'mish')])
+def test_two_layers_sums_in_one_dgrad_and_windowed_batchnorm_passes(dt, case):
+    """The operators behind the concatenation sums (engine._find_cats), each against what it replaces:
+    (1) cy_bn_act_fwd_fused with vec_ld: two layers write (mean, invstd, scale, shift) into column ranges of ONE [4][C1 + C2] block --
+        bit for bit what each writes into a block of its own, the other layer's columns untouched;
+    (2) cy_conv_dgrad_bn_sums over the joint pre-BN buffer [L1 | L2 (| B)] (row stride C1 + C2 + Cb) and that block: the input
+        gradient bit for bit the plain dgrad's, the table = what two cy_bn_act_bwd_reduce passes over the two layers produce;
+    (3) cy_bn_act_bwd_apply_fused with bins_ld / bins_c0: each layer's pass reading its column window of that table writes the dx,
+        parameter gradients and zeroed other table of a pass over a compact table with the same sums -- bit for bit."""
+    N, C1, C2, Cb, H, W, act = case
+    g = torch.Generator().manual_seed(C1 * 3 + H)
+    tdt = ops.torch_dtype(dt)
+    A = ops.ACT[act]
+    wide = C1 + C2 + Cb
+    CJ = C1 + C2
+    rawj = View.alloc(N, H, W, wide, dt); rawj.buf.copy_(torch.randn(rawj.buf.numel(), generator=g).to(tdt))
+    raws = [View(rawj.buf, 0, N, H, W, C1, wide, dt), View(rawj.buf, C1, N, H, W, C2, wide, dt)]
+    M = rawj.M
+    # ---- (1) forward passes: statistics tables -> vectors, joint block vs own blocks -------------------------------------------
+    vecj = torch.full((4, CJ), 7.0, device='cuda')
+    own = [torch.zeros(4, C1, device='cuda'), torch.zeros(4, C2, device='cuda')]
+    rows = ops.conv_stats_rows(M, C1)
+    other = torch.zeros(rows * 2 * CJ, device='cuda')
+    for k, (rv, C, c0) in enumerate(((raws[0], C1, 0), (raws[1], C2, C1))):
+        x32 = rv.to_nchw().float()
+        bins = torch.zeros(rows * 2 * C, device='cuda')
+        bins.view(rows, 2, C)[3, 0] = x32.sum((0, 2, 3)); bins.view(rows, 2, C)[5, 1] = (x32 * x32).sum((0, 2, 3))
+        gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+        y1, y2 = View.alloc(N, H, W, C, dt), View.alloc(N, H, W, C, dt)
+        ops.bn_act_fwd_fused(rv, y1, None, bins, rows, gam, bet, None, None, None, 0.03, 1e-5, own[k], other, A)
+        ops.bn_act_fwd_fused(rv, y2, None, bins, rows, gam, bet, None, None, None, 0.03, 1e-5, vecj[:, c0:c0 + C], other, A, vec_ld=CJ)
+        torch.cuda.synchronize()
+        assert torch.equal(y1.buf, y2.buf) and torch.equal(vecj[:, c0:c0 + C], own[k])
+        if k == 0:
+            assert float((vecj[:, C1:] - 7.0).abs().max()) == 0.0
+    # ---- (2) the dgrad that writes [dL1 | dL2] with both layers' sums ----------------------------------------------------------
+    Cp = 64                                        # the closing conv: CJ -> Cp, 1x1; its dgrad: Cp -> CJ
+    dy = View.alloc(N, H, W, Cp, dt); dy.buf.copy_((torch.randn(dy.buf.numel(), generator=g) * 0.5).to(tdt))
+    w = (torch.randn(Cp, CJ, 1, 1, generator=g) * 0.1).cuda()
+    _, wd = ops.pack_weights(w, Cp, CJ, dt)
+    g1, g2 = View.alloc(N, H, W, CJ, dt), View.alloc(N, H, W, CJ, dt)
+    tblj = torch.zeros(ops.conv_stats_rows(M, CJ) * 2 * CJ, device='cuda')
+    ops.conv_igemm(dy, wd, CJ, g1, 1, 1, 0, flags=ops.CONV_TRANSPOSED, tile=6)
+    catraw = View(rawj.buf, 0, N, H, W, CJ, wide, dt)
+    ops.conv_dgrad_bn_sums(dy, wd, CJ, g2, 1, 1, 0, catraw, vecj[0], vecj[1], vecj[2], vecj[3], A, tblj, flags=ops.CONV_TRANSPOSED, tile=6)
+    torch.cuda.synchronize()
+    assert torch.equal(g1.buf, g2.buf)
+    r16 = ops.conv_stats_rows(M, CJ)
+    sums = tblj.view(r16, 2, CJ).sum(0)
+    for k, (rv, C, c0) in enumerate(((raws[0], C1, 0), (raws[1], C2, C1))):
+        gk = View(g1.buf, c0, N, H, W, C, CJ, dt)
+        rr = ops.bn_bwd_rows(M, C, dt, False)
+        part = torch.zeros(rr * 2 * C, device='cuda')
+        ops.bn_act_bwd_reduce(rv, gk, own[k][0], own[k][1], own[k][2], own[k][3], A, part, rr)
+        torch.cuda.synchronize()
+        ref = part.view(rr, 2, C).sum(0)
+        torch.testing.assert_close(sums[:, c0:c0 + C], ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    # ---- (3) the two backward passes through column windows ---------------------------------------------------------------------
+    for k, (rv, C, c0) in enumerate(((raws[0], C1, 0), (raws[1], C2, C1))):
+        gk = View(g1.buf, c0, N, H, W, C, CJ, dt)
+        compact = tblj.view(r16, 2, CJ)[:, :, c0:c0 + C].contiguous().view(-1)
+        outs = []
+        for windowed in (False, True):
+            dx = View.alloc(N, H, W, C, dt)
+            gg, gb = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+            oth = torch.ones(256, device='cuda')
+            if windowed:
+                ops.bn_act_bwd_apply_fused(rv, gk, dx, None, False, own[k][0], own[k][1], own[k][2], own[k][3], tblj, r16, gg, gb, 0.5, oth, A,
+                                           bins_ld=CJ, bins_c0=c0)
+            else:
+                ops.bn_act_bwd_apply_fused(rv, gk, dx, None, False, own[k][0], own[k][1], own[k][2], own[k][3], compact, r16, gg, gb, 0.5, oth, A)
+            torch.cuda.synchronize()
+            outs.append((dx.buf.clone(), gg, gb, oth))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        assert float(outs[1][3].abs().max()) == 0.0 and float(outs[1][1].abs().max()) > 0.0
+    assert float(tblj.abs().max()) > 0.0           # (the shared table is left for the other layer's pass: not zeroed by its readers)
+
+
+@pytest.mark.parametrize('dtype,B,S,sib', [('f16', 4, 416, '1'), ('bf16', 2, 320, '0')])
+def test_concat_producers_sums_in_the_closing_dgrad_on_device(monkeypatch, dtype, B, S, sib):
+    """engine._find_cats on the device (the operators: the test above; the plan surgery: tests/test_round6_cpu.py on the simulator):
+    forced for all five CSP stages (CY_CAT_SUMS=2) against two reduce passes per stage (CY_CAT_SUMS=0), with the sibling fusion
+    (3-wide pre-BN buffer) and without (2-wide).  Ten layers lose their reduce pass.  On this random-init net a 16-bit gradient is
+    chaotic in its DIRECTION from one correct evaluation to the next (fp32 atomics order the BatchNorm statistics differently every
+    run: DESIGN.md section 4), so the bar is the engine's own spread: the BatchNorm parameter gradients of the ten layers -- which ARE
+    the folded sums -- differ from the reduce-pass engine's by no more than 1.5 x what two runs of the reduce-pass engine differ by,
+    with the same norms; three steps, so the tables of their own are found zeroed again."""
+    import os
+    import complex_yolov4_pytorch_amd.synthetic as syn
+    from complex_yolov4_pytorch_amd.models.darknet2pytorch import Darknet
+    cfg = os.path.join(os.path.dirname(__file__), '..', 'complex-yolov4-pytorch_amd', 'config', 'cfg', 'complex_yolov4.cfg')
+    monkeypatch.setenv('CY_SIBLING_FUSE', sib)
+    x, tg = syn.bev_images(B, S, seed=13).to(DEV), syn.targets(B, 5, S, seed=13).to(DEV)
+    res = {}
+    for tag, mode in (('a', '0'), ('b', '0'), ('c', '2')):
+        monkeypatch.setenv('CY_CAT_SUMS', mode)
+        torch.manual_seed(0)
+        m = Darknet(cfg, use_giou_loss=True, dtype=dtype)
+        sd = m.state_dict()
+        sd.update({k: syn.fill_tensor(k, tuple(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point})
+        m.load_state_dict(sd)
+        m.to(DEV).train()
+        for _ in range(3):
+            for p in m.parameters():
+                p.grad = None
+            loss, out = m(x, tg)
+            loss.backward()
+        eng = next(iter(m._engines.values()))
+        names = [eng._names(next(r for r in eng.plan.convs if r['idx'] == L))[1] for L in eng._cat_on]
+        res[tag] = (float(loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters()}, len(eng._cat), len(eng._cat_on), names,
+                    len(eng._sib))
+        m.release_engines()
+    assert res['a'][2] == 0 and res['c'][2] == 5 and res['c'][3] == 10 and res['c'][5] == (5 if sib != '0' else 0)
+    la, lb, lc = res['a'][0], res['b'][0], res['c'][0]
+    print('%s: loss with reduce passes %.5f / %.5f, with the sums in the closing dgrad %.5f' % (dtype, la, lb, lc))
+    assert abs(la - lc) <= 3e-2 * abs(la) + 2.0 * abs(la - lb)      # (bf16: two runs of ONE engine differ by 5 % on this net)
+    spread, diff, ratio = [], [], []
+    for bname in res['c'][4]:
+        for leaf in ('.weight', '.bias'):
+            ga, gb, gc = (res[t][1][bname + leaf] for t in 'abc')
+            assert bool(torch.isfinite(gc).all())
+            spread.append(float((gb - ga).norm() / ga.norm()))
+            diff.append(float((gc - ga).norm() / ga.norm()))
+            ratio.append(float(gc.norm() / ga.norm()))
+    spread.sort(); diff.sort(); ratio.sort()
+    print('BatchNorm parameter gradients of the ten layers, relative difference: run to run median %.2e max %.2e; sums in the dgrad '
+          'median %.2e max %.2e; norm ratio %.2f .. %.2f' % (spread[10], spread[-1], diff[10], diff[-1], ratio[0], ratio[-1]))
+    assert diff[10] <= 1.5 * spread[10] + 0.02 and diff[-1] <= 1.5 * spread[-1] + 0.05
+    assert 0.6 < ratio[0] and ratio[-1] < 1.6

@@ -131,7 +131,9 @@ def test_mini_cfg_all_block_types_tight_gradients(monkeypatch, dgrad_sums):
     assert max(errs.values()) < 2e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     eng = model._engine_for(torch.zeros(2, 3, 64, 64))
     marked = sum(len(b.get('dx_sums', {})) for b in eng.plan.bwd)
-    assert marked >= 3 and len(eng._sums_fused) == (marked if dgrad_sums else 0)
+    # (+ the two producers of a concatenation whose closing conv's dgrad takes both layers' sums: engine._find_cats)
+    assert marked >= 3 and len(eng._sums_fused) == ((marked + len(eng._cat_on)) if dgrad_sums else 0)
+    assert len(eng._cat_on) == (2 * len(eng._cat) if dgrad_sums == 2 else 0)
 
 
 def test_gradient_accumulation_and_zero_grad(monkeypatch):
