@@ -1142,8 +1142,8 @@ class Engine:
             idx, cop = rec['idx'], _pad32(rec['cout'])
             xv, raw, out = self.view(rec['x']), self.view(rec['raw']), self.view(rec['out'])
             res = self.view(rec['res']) if rec['res'] is not None else None
-            if xv.C % 64 or raw.C % 8 or self._pair(idx)[0] is not None:
-                continue
+            if xv.C % 64 or raw.C % 8 or self._pair(idx)[0] is not None or idx in self._cat_of:
+                continue      # (a concatenation's producers keep their vectors in a shared block: the two-phase kernel writes [4][C])
             _, bname = self._names(rec)
             vec, act = self.bnvec[idx], ops.ACT[rec['act']]
             tbl, other = self.stats_pair
