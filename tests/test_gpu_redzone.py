@@ -85,7 +85,10 @@ def test_benchmarked_default_mode_between_red_zones(monkeypatch, dtype):
         assert bad == [], bad
         assert all(bool(torch.isfinite(t).all()) for t in got)
         if steps == 1:
-            assert abs(float(got[0]) - float(det[0])) <= 2e-2 * abs(float(det[0]))
+            # (bf16: two runs of the SAME default-mode engine differ by up to 5 % in the loss on this random-init net -- 395.5 vs 415.9
+            # in test_gpu_r6's concatenation test --, the fp32 atomics ordering the BatchNorm statistics differently every run and 8
+            # mantissa bits amplifying it through 107 layers; f16 stays within 0.5 %.  A red zone that leaked would give NaN.)
+            assert abs(float(got[0]) - float(det[0])) <= (8e-2 if dtype == 'bf16' else 2e-2) * abs(float(det[0]))
         else:
             assert replayed >= 2
 
