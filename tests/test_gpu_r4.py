@@ -410,7 +410,8 @@ def test_model_forward_with_two_phase_convs_matches_the_separate_passes(monkeypa
           'outputs max |d| %.2e (%.2e)' % (res['2'][4], res['2'][0], res['0'][0], got, band, float((res['2'][1] - res['0'][1]).abs().max()),
                                           float((res['0b'][1] - res['0'][1]).abs().max())))
     assert res['2'][4] >= 30 and res['0'][4] == 0
-    assert abs(res['2'][0] - res['0'][0]) <= 5e-3 * abs(res['0'][0])
+    # (two runs of the separate-pass configuration differ by 0.2-0.4 % in the loss at this random init; 5e-3 was met by luck)
+    assert abs(res['2'][0] - res['0'][0]) <= 5e-3 * abs(res['0'][0]) + 2.0 * abs(res['0b'][0] - res['0'][0])
     assert got >= band - 0.15                                    # (both are draws of the same chaotic quantity at this random init)
     # running statistics: against the run-to-run spread of the separate-pass configuration itself (deep layers see inputs that
     # move with the atomics' order at this random init)
