@@ -600,7 +600,8 @@ def test_concat_producers_sums_in_the_closing_dgrad_on_device(monkeypatch, dtype
     assert res['a'][2] == 0 and res['c'][2] == 5 and res['c'][3] == 10 and res['c'][5] == (5 if sib != '0' else 0)
     la, lb, lc = res['a'][0], res['b'][0], res['c'][0]
     print('%s: loss with reduce passes %.5f / %.5f, with the sums in the closing dgrad %.5f' % (dtype, la, lb, lc))
-    assert abs(la - lc) <= 3e-2 * abs(la) + 2.0 * abs(la - lb)      # (bf16: two runs of ONE engine differ by 5 % on this net)
+    # (bf16: two runs of ONE engine differ by up to 5 % on this net -- and may by chance agree, so the band does not rest on them alone)
+    assert abs(la - lc) <= (8e-2 if dtype == 'bf16' else 3e-2) * abs(la) + 2.0 * abs(la - lb)
     spread, diff, ratio = [], [], []
     for bname in res['c'][4]:
         for leaf in ('.weight', '.bias'):
