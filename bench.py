@@ -588,12 +588,18 @@ def worker(a):
             # same run, profiles/r02_*, sit between the two).
             ridge = MFMA_PEAK_TFLOPS[a.dtype] * 1e12 / HBM_PEAK_BPS
             acc = {'mfma': [0.0, 0.0, 0.0, 0], 'hbm': [0.0, 0.0, 0.0, 0]}
+            # the HBM-bound class again by launch size: a launch that moves < 64 MB lasts 9-25 us, 6-8 us of which are fixed
+            # (dispatch, prologue, pipeline fill, tail: DESIGN.md section 5) -- its rate says nothing about the memory system
+            size = {'large (>= 64 MB algorithmic)': [0.0, 0.0, 0], 'small': [0.0, 0.0, 0]}
             for kind, fl, nb, ev0, ev1 in ops.PROFILER.records:
                 if kind not in ('igemm', 'igemm_sums') or nb <= 0:
                     continue
                 k = 'mfma' if fl / nb >= ridge else 'hbm'
                 t = max(ev0.elapsed_time(ev1), 1e-6)
                 acc[k][0] += fl; acc[k][1] += nb; acc[k][2] += t; acc[k][3] += 1
+                if k == 'hbm':
+                    sz = size['large (>= 64 MB algorithmic)' if nb >= 64e6 else 'small']
+                    sz[0] += nb; sz[1] += t; sz[2] += 1
             by_bound = {}
             for k, (fl, nb, ms, n) in acc.items():
                 if n:
@@ -601,6 +607,10 @@ def worker(a):
                                        tflops=round(fl / (ms * 1e-3) / 1e12, 1), gbs_algorithmic=round(nb / (ms * 1e-3) / 1e9, 1),
                                        frac=round((fl / (ms * 1e-3)) / (MFMA_PEAK_TFLOPS[a.dtype] * 1e12), 4) if k == 'mfma'
                                        else round((nb / (ms * 1e-3)) / HBM_PEAK_BPS, 4))
+            if 'hbm' in by_bound:
+                by_bound['hbm']['by_size'] = {k: dict(launches_per_step=n // 2, ms_per_step=round(ms / 2, 3),
+                                                      gbs_algorithmic=round(nb / (ms * 1e-3) / 1e9, 1), avg_launch_us=round(1e3 * ms / n, 1))
+                                              for k, (nb, ms, n) in size.items() if n}
         ops.PROFILER = None
         for e, sd in sides:
             e.side = sd
