@@ -533,8 +533,13 @@ def worker(a):
         step()
     if isinstance(net, RcclDataParallel):
         net.exposed_events = []      # (before, after) the compute stream's wait for the all-reduce stream, one pair per step
+    # (the supervisor's buffer map is host-side bookkeeping, tens of milliseconds with the allocator's snapshot: written while the
+    # queued warm-up steps are still executing, not between the synchronisation and the first timed step -- the GPU would sit
+    # idle there and start the timed region from a lowered clock)
+    if a.map_file and a.warmup > 0:
+        write_buffer_map(a.map_file, model, opt)
     sync()
-    if a.map_file:
+    if a.map_file and a.warmup == 0:
         write_buffer_map(a.map_file, model, opt)
     stage('timed region: %d steps' % a.steps)
     t0 = time.perf_counter()
